@@ -1,0 +1,324 @@
+"""CPU tests that pin the oracle (there is no TensorFlow and no reference fixture: parity unpinned).
+
+Known-answer tests of TF op semantics, dual formulations, float64 finite differences and the
+algebraic invariants listed in SURVEY.md section 8(c)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kat
+from oracle import ref_ops as R
+from oracle import ref_model as M
+
+F64 = torch.float64
+
+
+def _rand(rng, *shape):
+    return rng.standard_normal(shape)
+
+
+# ---------------------------------------------------------------- alignment KATs
+@pytest.mark.parametrize("k,s,H", [(3, 2, 8), (3, 1, 6), (1, 1, 4), (3, 2, 6)])
+def test_conv_reflect_matches_direct_loops(k, s, H):
+    """ops.py:65-95: reflect pad (2*pad split lo/hi) + VALID conv, vs loops."""
+    rng = np.random.default_rng(0)
+    x = _rand(rng, 2, H, H, 3)
+    vs = R.VarStore(F64, 1)
+    opt = {"sn": False}
+    pad = (k - 1) // 2
+    y = R.conv(vs, "d/c", torch.tensor(x), 5, opt, kernel=k, stride=s, pad=pad, use_bias=False)
+    w = vs.vars["d/c/kernel"].detach().numpy()
+    xp = kat.reflect_pad(x, pad, pad) if pad else x
+    y_ref = kat.conv2d_valid(xp, w, s)
+    assert y.shape == y_ref.shape == (2, H // s, H // s, 5)
+    np.testing.assert_allclose(y.detach().numpy(), y_ref, rtol=1e-12, atol=1e-12)
+
+
+def test_conv_stride2_window_centres():
+    """k3 s2 even H: reflect 1+1, output i reads padded rows 2i..2i+2 = input rows 2i-1..2i+1."""
+    H = 8
+    x = np.zeros((1, H, H, 1))
+    x[0, 3, 5, 0] = 1.0
+    vs = R.VarStore(F64, 1)
+    vs.load({"d/c/kernel": np.arange(9.0).reshape(3, 3, 1, 1) + 1})
+    y = R.conv(vs, "d/c", torch.tensor(x), 1, {"sn": False}, kernel=3, stride=2, pad=1, use_bias=False)
+    y = y.detach().numpy()[0, :, :, 0]
+    # input row 3 = 2*i - 1 + p  ->  (i=1,p=2), (i=2,p=0); col 5 -> (j=2,q=2), (j=3,q=0)
+    exp = np.zeros((4, 4))
+    exp[1, 2] = 9.0
+    exp[1, 3] = 7.0
+    exp[2, 2] = 3.0
+    exp[2, 3] = 1.0
+    np.testing.assert_array_equal(y, exp)
+
+
+@pytest.mark.parametrize("k,s", [(4, 2), (3, 1)])
+def test_deconv_same_matches_gradient_definition(k, s):
+    """ops.py:128: conv2d_transpose SAME == scatter definition (no kernel flip, pad_lo = 1)."""
+    rng = np.random.default_rng(1)
+    x = _rand(rng, 2, 5, 5, 4)
+    vs = R.VarStore(F64, 2)
+    y = R.deconv(vs, "generator/d", torch.tensor(x), 3, {"sn": False}, kernel=k, stride=s, use_bias=False)
+    w = vs.vars["generator/d/kernel"].detach().numpy()
+    assert w.shape == (k, k, 3, 4)
+    y_ref = kat.conv2d_transpose_same(x, w, s)
+    np.testing.assert_allclose(y.detach().numpy(), y_ref, rtol=1e-12, atol=1e-12)
+
+
+def test_deconv_is_adjoint_of_same_conv():
+    """<conv_same(a), b> == <a, conv2d_transpose(b)> for k4 s2 - the property TF defines it by."""
+    rng = np.random.default_rng(2)
+    a = _rand(rng, 1, 8, 8, 2)          # conv input  [B, sH, sW, Cout]
+    b = _rand(rng, 1, 4, 4, 3)          # conv output [B, H, W, Cin]
+    w = _rand(rng, 4, 4, 2, 3)          # [k,k,Cout,Cin]
+    _, lo, hi = kat.same_padding(8, 4, 2)
+    ap = np.pad(a, [(0, 0), (lo, hi), (lo, hi), (0, 0)])
+    fwd = kat.conv2d_valid(ap, w, 2)
+    bt = kat.conv2d_transpose_same(b, w, 2)
+    np.testing.assert_allclose((fwd * b).sum(), (a * bt).sum(), rtol=1e-12)
+
+
+# ---------------------------------------------------------------- DiffAugment closed forms
+@pytest.mark.parametrize("S", [7, 8, 32, 64])
+def test_diffaugment_closed_forms_bit_identical_to_literal(S):
+    rng = np.random.default_rng(S)
+    B = 6
+    x = rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32)
+    d = R.draw_diffaugment(rng, B, S)
+    shift, cs, off_max = R.diffaugment_params(S)
+    # force the extreme draws too
+    d["t_x"][0], d["t_y"][0] = -shift, shift
+    d["o_x"][1], d["o_y"][1] = 0, off_max - 1
+    lit = R.translation_literal(x, d["t_x"], d["t_y"])
+    ix = R.translation_index(S, d["t_x"])
+    iy = R.translation_index(S, d["t_y"])
+    closed = np.zeros_like(x)
+    for b in range(B):
+        for i in range(S):
+            for j in range(S):
+                if ix[b, i] >= 0 and iy[b, j] >= 0:
+                    closed[b, i, j] = x[b, ix[b, i], iy[b, j]]
+    assert np.array_equal(lit, closed)
+    litc = R.cutout_literal(x, d["o_x"], d["o_y"])
+    closedc = x * R.cutout_mask(S, d["o_x"], d["o_y"])[..., None]
+    assert np.array_equal(litc, closedc)
+    # torch formulation used by the model oracle
+    y = R.diffaugment(torch.tensor(x), d, "translation,cutout").numpy()
+    assert np.array_equal(y, closedc * 0 + R.cutout_mask(S, d["o_x"], d["o_y"])[..., None] * closed)
+
+
+def test_diffaugment_constants():
+    assert R.diffaugment_params(128) == (16, 64, 129)
+    assert R.diffaugment_params(256) == (32, 128, 257)
+    assert R.diffaugment_params(64) == (8, 32, 65)
+    assert R.diffaugment_params(32) == (4, 16, 33)
+
+
+# ---------------------------------------------------------------- spectral norm
+def test_spectral_norm_sigma_and_gradient():
+    rng = np.random.default_rng(3)
+    vs = R.VarStore(F64, 3)
+    w = torch.tensor(_rand(rng, 3, 3, 4, 6), requires_grad=True)
+    wn = R.spectral_norm(vs, "s", w)
+    W = w.detach().reshape(-1, 6)
+    u = vs.vars["s/u"]
+    v_hat = R.l2_normalize(u @ W.t())
+    u_hat = R.l2_normalize(v_hat @ W)
+    sigma = (v_hat @ W @ u_hat.t()).item()
+    assert abs(sigma - (v_hat @ W).norm().item()) < 1e-12            # sigma = ||v_hat W||
+    np.testing.assert_allclose(wn.detach().numpy(), (w / sigma).detach().numpy(), rtol=1e-13)
+    # closed-form backward: dW = (G - <G, Wn> v_hat^T u_hat) / sigma
+    G = torch.tensor(_rand(rng, 3, 3, 4, 6))
+    (gw,) = torch.autograd.grad((wn * G).sum(), w)
+    Gm = G.reshape(-1, 6)
+    exp = (Gm - (Gm * (W / sigma)).sum() * (v_hat.t() @ u_hat)) / sigma
+    np.testing.assert_allclose(gw.reshape(-1, 6).numpy(), exp.numpy(), rtol=1e-10, atol=1e-12)
+    assert torch.allclose(vs.state_updates["s/u"], u_hat)
+
+
+# ---------------------------------------------------------------- regulariser identity
+@pytest.mark.parametrize("c", [3, 8, 33])
+def test_ortho_cosine_closed_form(c):
+    rng = np.random.default_rng(c)
+    w = torch.tensor(_rand(rng, 3, 3, 5, c))
+    a = R.ortho_reg_loss(w, 1e-4, "ortho_cosine")
+    b = R.ortho_cosine_closed_form(w, 1e-4)
+    assert abs(a.item() - b.item()) <= 1e-14 * max(1.0, abs(a.item()))
+
+
+# ---------------------------------------------------------------- losses
+def test_hinge_flood_values_at_zero_logits():
+    z = torch.zeros(4, 1, dtype=F64)
+    assert R.discriminator_loss("hinge", z, z, 0).item() == 2.0
+    assert R.discriminator_loss("hinge", z, z, 0.1).item() == pytest.approx(2.0)
+    assert R.generator_loss("hinge", z, None, 0).item() == 0.0
+    assert R.generator_loss("hinge", z, None, 0.05).item() == pytest.approx(0.1)   # |0-0.05|+0.05
+    f = torch.full((4, 1), 1.0, dtype=F64, requires_grad=True)
+    L = R.generator_loss("hinge", f, None, 0.05)                   # -1 < 0.05 -> sign flips
+    (g,) = torch.autograd.grad(L, f)
+    assert torch.all(g > 0)
+
+
+# ---------------------------------------------------------------- model-level checks
+def _small_cfg(**kw):
+    base = dict(img_size=64, ch=8, batch_size=2, z_dim=64)
+    base.update(kw)
+    return M.Config(**base)
+
+
+def test_manifest_names_biggan128():
+    """Variable manifest of SURVEY R16/R17 (TF scope names)."""
+    cfg = M.Config(img_size=128, ch=8, batch_size=2)
+    tr = M.Trainer(cfg, torch.float32).build()
+    names = list(tr.vs.vars.keys())
+    assert cfg.z_split_sizes() == [96, 32, 32, 32, 32, 32]
+    for n, shape in [
+        ("generator/first/dense1/kernel", (96, 184)),
+        ("generator/first/dense1/u", (1, 184)),
+        ("generator/first/prelu/alpha", (184,)),
+        ("generator/first/dense2/kernel", (184, 16 * 16 * 8)),
+        ("generator/resblock_up_16/res1/batch_norm/pop_mean", (128,)),
+        ("generator/resblock_up_16/res1/batch_norm/beta/kernel", (32, 128)),
+        ("generator/resblock_up_16/res1/batch_norm/gamma/u", (1, 128)),
+        ("generator/resblock_up_16/res1/deconv_0/kernel", (4, 4, 128, 128)),
+        ("generator/resblock_up_16/res1/deconv_0/u", (1, 128)),
+        ("generator/resblock_up_8/res2/deconv_0/kernel", (3, 3, 64, 64)),
+        ("generator/resblock_up_8/skip/deconv_0/kernel", (4, 4, 64, 128)),
+        ("generator/self_attention/f_conv/kernel", (1, 1, 16, 2)),
+        ("generator/self_attention/h_conv/kernel", (1, 1, 16, 8)),
+        ("generator/self_attention/attn_conv/kernel", (1, 1, 8, 16)),
+        ("generator/self_attention/gamma", (1,)),
+        ("generator/batch_norm/moving_variance", (8,)),
+        ("generator/prelu/alpha", (8,)),
+        ("generator/G_logit/kernel", (3, 3, 8, 3)),
+        ("generator/G_logit/u", (1, 3)),
+        ("discriminator/resblock_down_1/res1/prelu/alpha", (3,)),
+        ("discriminator/resblock_down_1/res1/conv_0/kernel", (3, 3, 3, 8)),
+        ("discriminator/resblock_down_1/skip/conv_0/u", (1, 8)),
+        ("discriminator/self_attention/g_conv/bias", (1,)),
+        ("discriminator/resblock_down_16/res2/conv_0/kernel", (3, 3, 128, 128)),
+        ("discriminator/resblock/res1/conv_0/kernel", (3, 3, 128, 128)),
+        ("discriminator/prelu/alpha", (128,)),
+        ("discriminator/D_logit/kernel", (128, 1)),
+        ("discriminator/D_logit/bias", (1,)),
+        ("discriminator/D_logit/u", (1, 1)),
+    ]:
+        assert n in tr.vs.vars, n
+        assert tuple(tr.vs.vars[n].shape) == shape, (n, tuple(tr.vs.vars[n].shape))
+    assert not any("bias" in n for n in names if "resblock_down" in n)      # bias_in_d False
+    # SN'd weight counts: 42 in G-128, 22 in D-128
+    assert sum(n.startswith("generator") and n.endswith("/u") for n in names) == 42
+    assert sum(n.startswith("discriminator") and n.endswith("/u") for n in names) == 22
+
+
+def test_cumulative_scope_names_256():
+    cfg = M.Config(img_size=256, ch=8, batch_size=1)
+    tr = M.Trainer(cfg, torch.float32).build()
+    names = tr.vs.vars.keys()
+    assert "generator/resblock_up_8_0/res1/deconv_0/kernel" in names
+    assert "generator/resblock_up_8_0_1/res1/deconv_0/kernel" in names      # BigGAN.py:455 quirk
+    assert "discriminator/resblock_down_8_0_1/res1/conv_0/kernel" in names
+    assert cfg.z_split_sizes() == [88] + [28] * 6
+
+
+def test_sa_block_is_identity_at_gamma_zero():
+    cfg = _small_cfg()
+    vs = R.VarStore(F64, 0)
+    x = torch.tensor(np.random.default_rng(0).standard_normal((2, 8, 8, 16)))
+    y = R.self_attention_2(vs, "generator/self_attention", x, 16, {"sn": True, "self_attention_bias": True})
+    assert torch.equal(x, y)
+
+
+def test_step_runs_and_updates_expected_state():
+    cfg = _small_cfg()
+    tr = M.Trainer(cfg, F64).build()
+    M.perturb_for_parity(tr.vs)
+    batch = M.synthetic_batch(cfg, 5)
+    before = tr.vs.export()
+    out = tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"])
+    after = tr.vs.export()
+    assert np.isfinite(out["d_loss"].item())
+    changed = {k for k in before if not np.array_equal(before[k], after[k])}
+    # D step: every D trainable + u of BOTH nets + G's pop/moving stats; no G trainable
+    for k in before:
+        leaf = k.rsplit("/", 1)[-1]
+        if k.startswith("discriminator"):
+            assert k in changed, k
+        elif leaf in ("u", "pop_mean", "pop_var", "moving_mean", "moving_variance"):
+            assert k in changed, k
+        else:
+            assert k not in changed, k
+    out = tr.g_step(batch["z_g"], batch["aug_fake_g"])
+    after2 = tr.vs.export()
+    changed2 = {k for k in after if not np.array_equal(after[k], after2[k])}
+    for k in after:
+        leaf = k.rsplit("/", 1)[-1]
+        if k.startswith("generator"):
+            assert k in changed2, k
+        elif leaf == "u":
+            if after[k].size > 1:          # a 1-element u is already +-1 after the first step
+                assert k in changed2, k
+        else:
+            assert k not in changed2, k
+    assert out["g_reg"].item() > 0
+
+
+def test_finite_difference_gradients():
+    """float64 central differences on a handful of D and G parameters."""
+    cfg = _small_cfg(ch=8, z_dim=64)
+    tr = M.Trainer(cfg, F64).build()
+    M.perturb_for_parity(tr.vs)
+    batch = M.synthetic_batch(cfg, 11)
+
+    def d_loss():
+        with torch.no_grad():
+            return tr.d_forward(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"])["d_loss"].item()
+
+    def g_loss():
+        with torch.no_grad():
+            return tr.g_forward(batch["z_g"], batch["aug_fake_g"])["g_loss"].item()
+
+    gd = tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], apply=False)["grads"]
+    gg = tr.g_step(batch["z_g"], batch["aug_fake_g"], apply=False)["grads"]
+    tr.vs.freeze_uv = True        # u_hat / v_hat are stop-gradient constants of the run (ops.py:738-739)
+    rng = np.random.default_rng(0)
+    eps = 1e-6
+    checks = [
+        (d_loss, gd, "discriminator/resblock_down_2/res1/conv_0/kernel"),
+        (d_loss, gd, "discriminator/self_attention/f_conv/kernel"),
+        (d_loss, gd, "discriminator/resblock_down_1/res1/prelu/alpha"),
+        (d_loss, gd, "discriminator/D_logit/kernel"),
+        (g_loss, gg, "generator/resblock_up_4/res1/deconv_0/kernel"),
+        (g_loss, gg, "generator/resblock_up_2/res2/batch_norm/gamma/kernel"),
+        (g_loss, gg, "generator/self_attention/gamma"),
+        (g_loss, gg, "generator/first/dense2/kernel"),
+        (g_loss, gg, "generator/batch_norm/gamma"),
+        (g_loss, gg, "generator/G_logit/kernel"),
+    ]
+    for fn, grads, name in checks:
+        p = tr.vs.vars[name]
+        flat = p.detach().view(-1)
+        for idx in rng.integers(0, flat.numel(), 2):
+            old = flat[idx].item()
+            with torch.no_grad():
+                flat[idx] = old + eps
+            lp = fn()
+            with torch.no_grad():
+                flat[idx] = old - eps
+            lm = fn()
+            with torch.no_grad():
+                flat[idx] = old
+            fd = (lp - lm) / (2 * eps)
+            an = grads[name].reshape(-1)[idx].item()
+            assert abs(fd - an) <= 1e-5 * max(1e-3, abs(an), abs(fd)) + 1e-9, (name, idx, fd, an)
+
+
+def test_adam_tf_form():
+    opt = M.AdamTF(2e-4, 0.0, 0.9)
+    p = {"a": torch.tensor([1.0, -2.0], dtype=F64)}
+    g = {"a": torch.tensor([0.5, -0.25], dtype=F64)}
+    opt.step(p, g)
+    lr_t = 2e-4 * np.sqrt(1 - 0.9)
+    v = 0.1 * np.array([0.25, 0.0625])
+    exp = np.array([1.0, -2.0]) - lr_t * np.array([0.5, -0.25]) / (np.sqrt(v) + 1e-8)
+    np.testing.assert_allclose(p["a"].numpy(), exp, rtol=1e-14)
