@@ -1,0 +1,389 @@
+// augment_loss.hip - DiffAugment fused gather (DiffAugment_tf.py:8-73), hinge + flood losses
+// (ops.py:788-797, 832-840, 847-848) and the orthogonal-cosine regulariser rows (utils.py:180-235).
+#include "common.h"
+
+namespace bg {
+
+#define AL_BLOCK 256
+#define DA_MAXC 4
+
+// integer constants of rand_translation / rand_cutout for image size S (DiffAugment_tf.py:43,56)
+__host__ __device__ inline int da_cutout_size(int S) { return (int)((float)S * 0.5f + 0.5f); }
+
+struct DaArgs {
+    const float *u_b, *u_s, *u_c;
+    const int32_t *t_x, *t_y, *o_x, *o_y;
+    int N, S, C, policy;
+};
+
+// color ops on one pixel (brightness :20-23, saturation :26-30); contrast needs the sample mean
+__device__ __forceinline__ void da_color_pre(float (&v)[DA_MAXC], int C, float ub, float us) {
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < DA_MAXC; ++c)
+        if (c < C) {
+            v[c] += ub - 0.5f;
+            m += v[c];
+        }
+    m /= (float)C;
+    const float mag = us * 2.f;
+#pragma unroll
+    for (int c = 0; c < DA_MAXC; ++c)
+        if (c < C) v[c] = (v[c] - m) * mag + m;
+}
+
+// per-sample sum of the brightness/saturation-adjusted image (reduce_mean of rand_contrast, :35)
+__global__ __launch_bounds__(AL_BLOCK) void da_mean_kernel(const float* __restrict__ x, DaArgs a, float* sums) {
+    __shared__ float sh[4];
+    const int n = blockIdx.y;
+    const int64_t px = (int64_t)a.S * a.S;
+    const float ub = a.u_b[n], us = a.u_s[n];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * AL_BLOCK + threadIdx.x; i < px; i += (int64_t)gridDim.x * AL_BLOCK) {
+        const float* p = x + ((int64_t)n * px + i) * a.C;
+        float v[DA_MAXC];
+#pragma unroll
+        for (int c = 0; c < DA_MAXC; ++c) v[c] = c < a.C ? p[c] : 0.f;
+        da_color_pre(v, a.C, ub, us);
+#pragma unroll
+        for (int c = 0; c < DA_MAXC; ++c)
+            if (c < a.C) s += v[c];
+    }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) atomicAdd(&sums[n], s);
+}
+
+__device__ __forceinline__ bool da_cut(const DaArgs& a, int n, int i, int j) {
+    // DiffAugment_tf.py:53-66: zero rows [max(0,o-cs/2), min(S-1,o-cs/2+cs-1)] x cols likewise
+    const int cs = da_cutout_size(a.S);
+    const int r0 = max(0, a.o_x[n] - cs / 2), r1 = min(a.S - 1, a.o_x[n] - cs / 2 + cs - 1);
+    const int c0 = max(0, a.o_y[n] - cs / 2), c1 = min(a.S - 1, a.o_y[n] - cs / 2 + cs - 1);
+    return i >= r0 && i <= r1 && j >= c0 && j <= c1;
+}
+
+__global__ __launch_bounds__(AL_BLOCK) void da_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, DaArgs a,
+                                                           const float* sums) {
+    const int64_t px = (int64_t)a.S * a.S;
+    const int64_t total = (int64_t)a.N * px;
+    const bool color = a.policy & 1, trans = a.policy & 2, cut = a.policy & 4;
+    for (int64_t idx = (int64_t)blockIdx.x * AL_BLOCK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * AL_BLOCK) {
+        const int n = (int)(idx / px);
+        const int r = (int)(idx % px);
+        const int i = r / a.S, j = r % a.S;
+        float v[DA_MAXC];
+#pragma unroll
+        for (int c = 0; c < DA_MAXC; ++c) v[c] = 0.f;
+        bool live = !(cut && da_cut(a, n, i, j));
+        int si = i, sj = j;
+        if (trans) {                                  // DiffAugment_tf.py:40-50: out[i,j] = x[i+t_x, j+t_y] or 0
+            si = i + a.t_x[n];
+            sj = j + a.t_y[n];
+            live = live && si >= 0 && si < a.S && sj >= 0 && sj < a.S;
+        }
+        if (live) {
+            const float* p = x + (((int64_t)n * a.S + si) * a.S + sj) * a.C;
+#pragma unroll
+            for (int c = 0; c < DA_MAXC; ++c) v[c] = c < a.C ? p[c] : 0.f;
+            if (color) {
+                da_color_pre(v, a.C, a.u_b[n], a.u_s[n]);
+                const float m = sums[n] / (float)(px * a.C);          // rand_contrast :33-37
+                const float mag = a.u_c[n] + 0.5f;
+#pragma unroll
+                for (int c = 0; c < DA_MAXC; ++c)
+                    if (c < a.C) v[c] = (v[c] - m) * mag + m;
+            }
+        }
+        float* q = y + idx * a.C;
+#pragma unroll
+        for (int c = 0; c < DA_MAXC; ++c)
+            if (c < a.C) q[c] = v[c];
+    }
+}
+
+// gradient w.r.t. the colour-adjusted image x3 at source pixel (p,q): dy[p - t_x, q - t_y] * mask, or 0
+__device__ __forceinline__ bool da_bwd_src(const DaArgs& a, int n, int p, int q, int& i, int& j) {
+    i = p;
+    j = q;
+    if (a.policy & 2) {
+        i = p - a.t_x[n];
+        j = q - a.t_y[n];
+        if (i < 0 || i >= a.S || j < 0 || j >= a.S) return false;
+    }
+    if ((a.policy & 4) && da_cut(a, n, i, j)) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(AL_BLOCK) void da_bwd_sum_kernel(const float* __restrict__ dy, DaArgs a, float* sums) {
+    __shared__ float sh[4];
+    const int n = blockIdx.y;
+    const int64_t px = (int64_t)a.S * a.S;
+    float s = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * AL_BLOCK + threadIdx.x; r < px; r += (int64_t)gridDim.x * AL_BLOCK) {
+        int i, j;
+        if (da_bwd_src(a, n, (int)(r / a.S), (int)(r % a.S), i, j)) {
+            const float* p = dy + (((int64_t)n * a.S + i) * a.S + j) * a.C;
+#pragma unroll
+            for (int c = 0; c < DA_MAXC; ++c)
+                if (c < a.C) s += p[c];
+        }
+    }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) atomicAdd(&sums[n], s);
+}
+
+__global__ __launch_bounds__(AL_BLOCK) void da_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, DaArgs a,
+                                                           const float* sums) {
+    const int64_t px = (int64_t)a.S * a.S;
+    const int64_t total = (int64_t)a.N * px;
+    const bool color = a.policy & 1;
+    for (int64_t idx = (int64_t)blockIdx.x * AL_BLOCK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * AL_BLOCK) {
+        const int n = (int)(idx / px);
+        const int r = (int)(idx % px);
+        float g[DA_MAXC];
+#pragma unroll
+        for (int c = 0; c < DA_MAXC; ++c) g[c] = 0.f;
+        int i, j;
+        if (da_bwd_src(a, n, r / a.S, r % a.S, i, j)) {
+            const float* p = dy + (((int64_t)n * a.S + i) * a.S + j) * a.C;
+#pragma unroll
+            for (int c = 0; c < DA_MAXC; ++c) g[c] = c < a.C ? p[c] : 0.f;
+        }
+        if (color) {
+            // contrast: x3 = (x2 - m) c + m, m = mean_hwc(x2)  ->  dx2 = c dx3 + (1-c) mean_hwc(dx3)
+            const float cm = a.u_c[n] + 0.5f;
+            const float mg = sums[n] / (float)(px * a.C);
+            float mc = 0.f;
+#pragma unroll
+            for (int c = 0; c < DA_MAXC; ++c)
+                if (c < a.C) {
+                    g[c] = cm * g[c] + (1.f - cm) * mg;
+                    mc += g[c];
+                }
+            // saturation: x2 = (x1 - mean_c) s + mean_c  ->  dx1 = s dx2 + (1-s) mean_c(dx2)
+            mc /= (float)a.C;
+            const float sm = a.u_s[n] * 2.f;
+#pragma unroll
+            for (int c = 0; c < DA_MAXC; ++c)
+                if (c < a.C) g[c] = sm * g[c] + (1.f - sm) * mc;
+        }
+        float* q = dx + idx * a.C;
+#pragma unroll
+        for (int c = 0; c < DA_MAXC; ++c)
+            if (c < a.C) q[c] = g[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// hinge + flood
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AL_BLOCK) void hinge_d_sums_kernel(const float* real, const float* fake, float* sums, int n) {
+    __shared__ float sh[4];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n; i += AL_BLOCK) {
+        a += fmaxf(1.f - real[i], 0.f);
+        b += fmaxf(1.f + fake[i], 0.f);
+    }
+    a = block_sum_256(a, sh);
+    b = block_sum_256(b, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[0], a);
+        atomicAdd(&sums[1], b);
+    }
+}
+
+__global__ __launch_bounds__(AL_BLOCK) void hinge_d_grad_kernel(const float* real, const float* fake, const float* sums,
+                                                                 double n_global, float flood, float* d_real,
+                                                                 float* d_fake, float* loss_out, int n) {
+    const float inv = (float)(1.0 / n_global);
+    float L = sums[0] * inv + sums[1] * inv;                  // ops.py:788-792
+    float sgn = 1.f;
+    if (flood != 0.f) {                                       // ops.py:794-795, 847-848
+        const float d = L - flood;
+        sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        L = fabsf(d) + flood;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) *loss_out = L;
+    for (int i = blockIdx.x * AL_BLOCK + threadIdx.x; i < n; i += gridDim.x * AL_BLOCK) {
+        d_real[i] = (1.f - real[i]) > 0.f ? -sgn * inv : 0.f;
+        d_fake[i] = (1.f + fake[i]) > 0.f ? sgn * inv : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(AL_BLOCK) void hinge_g_sums_kernel(const float* fake, float* sums, int n) {
+    __shared__ float sh[4];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += AL_BLOCK) a += fake[i];
+    a = block_sum_256(a, sh);
+    if (threadIdx.x == 0) atomicAdd(&sums[0], a);
+}
+
+__global__ __launch_bounds__(AL_BLOCK) void hinge_g_grad_kernel(const float* sums, double n_global, float flood,
+                                                                 float* d_fake, float* loss_out, int n) {
+    const float inv = (float)(1.0 / n_global);
+    float L = -sums[0] * inv;                                 // ops.py:832-833
+    float sgn = 1.f;
+    if (flood != 0.f) {                                       // ops.py:837-838
+        const float d = L - flood;
+        sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        L = fabsf(d) + flood;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) *loss_out = L;
+    for (int i = blockIdx.x * AL_BLOCK + threadIdx.x; i < n; i += gridDim.x * AL_BLOCK) d_fake[i] = -sgn * inv;
+}
+
+// ------------------------------------------------------------------------------------------
+// ortho-cosine regulariser on the Gram matrix A [c,c]: one block per row
+//   Ahat = l2n_rows(A); R[i,j] = (sum_k Ahat[i,k] - Ahat[i,j]) / sqrt(c-1); loss += scale/2 sum R^2
+//   dR = scale R ; dAhat[i,j] = (sum_j' dR[i,j'] - dR[i,j]) / sqrt(c-1) ;
+//   dA[i,j] = rn_i (dAhat[i,j] - Ahat[i,j] sum_k dAhat[i,k] Ahat[i,k])   (when sum A^2 >= 1e-12)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AL_BLOCK) void ortho_cosine_kernel(const float* __restrict__ A, float scale,
+                                                                 float* loss_accum, float* __restrict__ dA, int c) {
+    __shared__ float sh[4];
+    const int i = blockIdx.x;
+    const float* a = A + (int64_t)i * c;
+    float ss = 0.f, sa = 0.f;
+    for (int k = threadIdx.x; k < c; k += AL_BLOCK) {
+        const float t = a[k];
+        ss += t * t;
+        sa += t;
+    }
+    ss = block_sum_256(ss, sh);
+    sa = block_sum_256(sa, sh);
+    const bool clamped = ss < 1e-12f;
+    const float rn = rsqrtf(fmaxf(ss, 1e-12f));
+    const float r = sa * rn;                                   // sum_k Ahat[i,k]
+    const float isq = c > 1 ? rsqrtf((float)(c - 1)) : 0.f;   // l2n of an all-zero row of (1 - I) is 0
+    // sum_j R^2, sum_j R, sum_j R*Ahat
+    float s2 = 0.f, s1 = 0.f, sra = 0.f;
+    for (int k = threadIdx.x; k < c; k += AL_BLOCK) {
+        const float ah = a[k] * rn;
+        const float R = (r - ah) * isq;
+        s2 += R * R;
+        s1 += R;
+        sra += R * ah;
+    }
+    s2 = block_sum_256(s2, sh);
+    s1 = block_sum_256(s1, sh);
+    sra = block_sum_256(sra, sh);
+    if (threadIdx.x == 0) atomicAdd(loss_accum, 0.5f * scale * s2);
+    if (!dA) return;
+    // dAhat[j] = scale*isq*(s1 - R_j); T = sum_k dAhat[k]*Ahat[k] = scale*isq*(s1*r - sra)
+    const float T = scale * isq * (s1 * r - sra);
+    float* o = dA + (int64_t)i * c;
+    for (int k = threadIdx.x; k < c; k += AL_BLOCK) {
+        const float ah = a[k] * rn;
+        const float R = (r - ah) * isq;
+        const float dah = scale * isq * (s1 - R);
+        o[k] = clamped ? rn * dah : rn * (dah - ah * T);
+    }
+}
+
+}  // namespace bg
+
+using namespace bg;
+
+static int da_check(const void* a, const void* b, int N, int S, int C, int policy) {
+    BG_REQUIRE(a && b && N > 0 && S > 0 && C > 0 && C <= DA_MAXC, "bg_diffaugment: bad argument (C must be <= %d)", DA_MAXC);
+    BG_REQUIRE((policy & ~7) == 0, "bg_diffaugment: unknown policy bits");
+    return BG_OK;
+}
+
+extern "C" {
+
+int bg_diffaugment_fwd(const float* x, float* y, const float* u_b, const float* u_s, const float* u_c,
+                       const int32_t* t_x, const int32_t* t_y, const int32_t* o_x, const int32_t* o_y, int N, int S,
+                       int C, int policy, float* mean_ws, void* stream) {
+    int rc = da_check(x, y, N, S, C, policy);
+    if (rc) return rc;
+    BG_REQUIRE(!(policy & 1) || (u_b && u_s && u_c && mean_ws), "bg_diffaugment_fwd: color needs u_b,u_s,u_c,mean_ws");
+    BG_REQUIRE(!(policy & 2) || (t_x && t_y), "bg_diffaugment_fwd: translation needs t_x,t_y");
+    BG_REQUIRE(!(policy & 4) || (o_x && o_y), "bg_diffaugment_fwd: cutout needs o_x,o_y");
+    hipStream_t s = as_stream(stream);
+    DaArgs a{u_b, u_s, u_c, t_x, t_y, o_x, o_y, N, S, C, policy};
+    const int64_t px = (int64_t)S * S;
+    if (policy & 1) {
+        if (hipMemsetAsync(mean_ws, 0, sizeof(float) * N, s) != hipSuccess) {
+            set_error("bg_diffaugment_fwd: memset failed");
+            return BG_ERR_LAUNCH;
+        }
+        int bx = (int)((px + AL_BLOCK * 8 - 1) / (AL_BLOCK * 8));
+        if (bx < 1) bx = 1;
+        hipLaunchKernelGGL(da_mean_kernel, dim3(bx, N), dim3(AL_BLOCK), 0, s, x, a, mean_ws);
+        BG_LAUNCH_CHECK();
+    }
+    int64_t blocks = ((int64_t)N * px + AL_BLOCK - 1) / AL_BLOCK;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(da_fwd_kernel, dim3((unsigned)blocks), dim3(AL_BLOCK), 0, s, x, y, a, mean_ws);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_diffaugment_bwd(const float* dy, float* dx, const float* u_s, const float* u_c, const int32_t* t_x,
+                       const int32_t* t_y, const int32_t* o_x, const int32_t* o_y, int N, int S, int C, int policy,
+                       float* mean_ws, void* stream) {
+    int rc = da_check(dy, dx, N, S, C, policy);
+    if (rc) return rc;
+    BG_REQUIRE(!(policy & 1) || (u_s && u_c && mean_ws), "bg_diffaugment_bwd: color needs u_s,u_c,mean_ws");
+    BG_REQUIRE(!(policy & 2) || (t_x && t_y), "bg_diffaugment_bwd: translation needs t_x,t_y");
+    BG_REQUIRE(!(policy & 4) || (o_x && o_y), "bg_diffaugment_bwd: cutout needs o_x,o_y");
+    hipStream_t s = as_stream(stream);
+    DaArgs a{nullptr, u_s, u_c, t_x, t_y, o_x, o_y, N, S, C, policy};
+    const int64_t px = (int64_t)S * S;
+    if (policy & 1) {
+        if (hipMemsetAsync(mean_ws, 0, sizeof(float) * N, s) != hipSuccess) {
+            set_error("bg_diffaugment_bwd: memset failed");
+            return BG_ERR_LAUNCH;
+        }
+        int bx = (int)((px + AL_BLOCK * 8 - 1) / (AL_BLOCK * 8));
+        if (bx < 1) bx = 1;
+        hipLaunchKernelGGL(da_bwd_sum_kernel, dim3(bx, N), dim3(AL_BLOCK), 0, s, dy, a, mean_ws);
+        BG_LAUNCH_CHECK();
+    }
+    int64_t blocks = ((int64_t)N * px + AL_BLOCK - 1) / AL_BLOCK;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(da_bwd_kernel, dim3((unsigned)blocks), dim3(AL_BLOCK), 0, s, dy, dx, a, mean_ws);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_hinge_d_sums(const float* real, const float* fake, float* sums, int n, void* stream) {
+    BG_REQUIRE(real && fake && sums && n > 0, "bg_hinge_d_sums: bad argument");
+    hipLaunchKernelGGL(hinge_d_sums_kernel, dim3(1), dim3(AL_BLOCK), 0, as_stream(stream), real, fake, sums, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_hinge_d_grad(const float* real, const float* fake, const float* sums, double n_global, float flood,
+                    float* d_real, float* d_fake, float* loss_out, int n, void* stream) {
+    BG_REQUIRE(real && fake && sums && d_real && d_fake && n > 0 && n_global > 0, "bg_hinge_d_grad: bad argument");
+    hipLaunchKernelGGL(hinge_d_grad_kernel, dim3((n + AL_BLOCK - 1) / AL_BLOCK), dim3(AL_BLOCK), 0, as_stream(stream),
+                       real, fake, sums, n_global, flood, d_real, d_fake, loss_out, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_hinge_g_sums(const float* fake, float* sums, int n, void* stream) {
+    BG_REQUIRE(fake && sums && n > 0, "bg_hinge_g_sums: bad argument");
+    hipLaunchKernelGGL(hinge_g_sums_kernel, dim3(1), dim3(AL_BLOCK), 0, as_stream(stream), fake, sums, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_hinge_g_grad(const float* sums, double n_global, float flood, float* d_fake, float* loss_out, int n,
+                    void* stream) {
+    BG_REQUIRE(sums && d_fake && n > 0 && n_global > 0, "bg_hinge_g_grad: bad argument");
+    hipLaunchKernelGGL(hinge_g_grad_kernel, dim3((n + AL_BLOCK - 1) / AL_BLOCK), dim3(AL_BLOCK), 0, as_stream(stream),
+                       sums, n_global, flood, d_fake, loss_out, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_ortho_cosine_fwd_bwd(const float* A, float scale, float* loss_accum, float* dA, int c, void* stream) {
+    BG_REQUIRE(A && loss_accum && c > 0, "bg_ortho_cosine_fwd_bwd: bad argument");
+    hipLaunchKernelGGL(ortho_cosine_kernel, dim3(c), dim3(AL_BLOCK), 0, as_stream(stream), A, scale, loss_accum, dA, c);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// core.hip - ABI bookkeeping: version, thread-local error string, optional per-launch HIP-event
+// timing of the MFMA GEMM families (bench.py's roofline leg).
+#include <stdarg.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace bg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct ProfRec {
+    hipEvent_t e0, e1;
+    double flops;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;     // completed-but-uncollected launches
+static std::vector<ProfRec> g_prof_pool;     // reusable event pairs
+
+ProfScope::ProfScope(hipStream_t s, double flops) : stream(s), slot(-1) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    if (!g_prof_pool.empty()) {
+        r = g_prof_pool.back();
+        g_prof_pool.pop_back();
+    } else {
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    }
+    r.flops = flops;
+    (void)hipEventRecord(r.e0, s);
+    g_prof_recs.push_back(r);
+    slot = (int)g_prof_recs.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (slot < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[slot].e1, stream);
+}
+
+}  // namespace bg
+
+extern "C" {
+
+int bg_abi_version(void) { return BG_ABI_VERSION; }
+const char* bg_last_error(void) { return bg::g_err; }
+const char* bg_target_arch(void) { return "gfx950"; }
+
+void bg_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(bg::g_prof_mu);
+    bg::g_prof_on = on != 0;
+}
+
+void bg_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(bg::g_prof_mu);
+    for (auto& r : bg::g_prof_recs) bg::g_prof_pool.push_back(r);
+    bg::g_prof_recs.clear();
+}
+
+int bg_prof_collect(double* total_ms, double* total_flops, int64_t* launches) {
+    std::lock_guard<std::mutex> lk(bg::g_prof_mu);
+    double ms = 0, fl = 0;
+    int64_t n = 0;
+    for (auto& r : bg::g_prof_recs) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) continue;
+        ms += t;
+        fl += r.flops;
+        ++n;
+    }
+    for (auto& r : bg::g_prof_recs) bg::g_prof_pool.push_back(r);
+    bg::g_prof_recs.clear();
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (launches) *launches = n;
+    return BG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,991 @@
+// elementwise.hip - HBM-bound kernels of the BigGAN step: spectral-norm power iteration, batch
+// statistics, (conditional) batch-norm + PReLU forward/backward, pooling, softmax, small
+// elementwise ops, bias gradient, fused TF-Adam + EMA.  16-byte vector accesses, wave64 shuffle
+// reductions, grid-stride loops capped at 2048 blocks (256 CUs x 8).
+#include "common.h"
+
+namespace bg {
+
+#define EW_BLOCK 256
+#define EW_MAX_BLOCKS 2048
+
+static inline int ew_grid(int64_t work_items) {
+    int64_t b = (work_items + EW_BLOCK - 1) / EW_BLOCK;
+    if (b > EW_MAX_BLOCKS) b = EW_MAX_BLOCKS;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void stg4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ==========================================================================================
+// column-reduction skeleton: rows x C matrix (optionally segmented by blockIdx.y), each thread owns
+// VEC consecutive columns and a strided subset of the block's rows; NQ quantities are reduced
+// over rows, combined across the block's row-lanes through LDS and added to out[q*qstride + seg*C + c]
+// with one float atomic per column per block.
+// ==========================================================================================
+template <int NQ, int VEC, class Fn>
+__global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(Fn fn, float* out, int64_t qstride,
+                                                             int64_t rows_per_seg, int C, int rows_per_block) {
+    __shared__ float red[NQ * EW_BLOCK * VEC];   // VEC*NQ floats per thread
+    const int CV = C / VEC;                      // vector columns
+    const int tx = CV < EW_BLOCK ? CV : EW_BLOCK;
+    const int lanes = EW_BLOCK / tx;             // row-lanes per block
+    const int cq = threadIdx.x % tx, rl = threadIdx.x / tx;
+    const int seg = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows_per_seg) r1 = rows_per_seg;
+    for (int cbase = 0; cbase < CV; cbase += tx) {
+        const int cv = cbase + cq;
+        float acc[NQ][VEC];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[q][j] = 0.f;
+        if (cv < CV && rl < lanes) {
+            for (int64_t r = r0 + rl; r < r1; r += lanes) fn(seg, r, cv * VEC, acc);
+        }
+        // combine row-lanes
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) red[(q * VEC + j) * EW_BLOCK + threadIdx.x] = acc[q][j];
+        __syncthreads();
+        if (rl == 0 && cv < CV) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    float s = 0.f;
+                    for (int l = 0; l < lanes; ++l) s += red[(q * VEC + j) * EW_BLOCK + l * tx + cq];
+                    atomicAdd(&out[q * qstride + (int64_t)seg * C + cv * VEC + j], s);
+                }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NQ, class Fn>
+static void launch_colreduce(Fn fn, float* out, int64_t qstride, int64_t rows_per_seg, int nseg, int C,
+                             hipStream_t s) {
+    // ~1024 blocks in total, at least 32 rows per block
+    int64_t blocks_per_seg = (1024 + nseg - 1) / nseg;
+    int64_t rpb = (rows_per_seg + blocks_per_seg - 1) / blocks_per_seg;
+    if (rpb < 32) rpb = 32;
+    blocks_per_seg = (rows_per_seg + rpb - 1) / rpb;
+    dim3 grid((unsigned)blocks_per_seg, (unsigned)nseg);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((colreduce_kernel<NQ, 4, Fn>), grid, dim3(EW_BLOCK), 0, s, fn, out, qstride, rows_per_seg,
+                           C, (int)rpb);
+    else
+        hipLaunchKernelGGL((colreduce_kernel<NQ, 1, Fn>), grid, dim3(EW_BLOCK), 0, s, fn, out, qstride, rows_per_seg,
+                           C, (int)rpb);
+}
+
+template <int VEC>
+__device__ __forceinline__ void loadv(const float* p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        float4 t = ldg4(p);
+        v[0] = t.x;
+        v[1] = t.y;
+        v[2] = t.z;
+        v[VEC - 1] = t.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = p[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// batch statistics (tf.nn.moments, ops.py:630)
+// ------------------------------------------------------------------------------------------
+struct BnStatsFn {
+    const float* x;
+    int C;
+    template <int VEC>
+    __device__ __forceinline__ void operator()(int, int64_t r, int c, float (&acc)[2][VEC]) const {
+        float v[VEC];
+        loadv<VEC>(x + r * C + c, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            acc[0][j] += v[j];
+            acc[1][j] += v[j] * v[j];
+        }
+    }
+};
+
+__global__ void bn_finalize_kernel(const float* sums, double count, float eps, float momentum, int unbiased,
+                                   float* mean, float* rstd, float* mm, float* mv, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = (double)sums[c] / count;
+    double var = (double)sums[C + c] / count - m * m;
+    if (var < 0) var = 0;
+    mean[c] = (float)m;
+    rstd[c] = rsqrtf((float)var + eps);
+    if (mm) mm[c] = mm[c] * momentum + (float)m * (1.f - momentum);
+    if (mv) {
+        double vv = var;
+        if (unbiased && count > 1) vv = var * (count / (count - 1.0));
+        mv[c] = mv[c] * momentum + (float)vv * (1.f - momentum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// (conditional) batch-norm apply + PReLU
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float prelu_f(float v, float a) { return v > 0.f ? v : a * v; }
+// TF gradient of relu(x) + a*(x-|x|)/2: 1 for x>0, a for x<0, a/2 at x==0
+__device__ __forceinline__ float prelu_d(float v, float a) { return v > 0.f ? 1.f : (v < 0.f ? a : 0.5f * a); }
+
+template <int VEC>
+__global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_fwd_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ rstd,
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, int per_sample,
+                                                                     const float* __restrict__ alpha,
+                                                                     float* __restrict__ y, int N, int HW, int C) {
+    const int CV = C / VEC;
+    const int64_t total = (int64_t)N * HW * CV;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c = (int)(i % CV) * VEC;
+        const int n = (int)(i / ((int64_t)HW * CV));
+        const float* gp = gamma + (per_sample ? (int64_t)n * C : 0) + c;
+        const float* bp = beta + (per_sample ? (int64_t)n * C : 0) + c;
+        float xv[VEC], mu[VEC], rs[VEC], ga[VEC], be[VEC], al[VEC], out[VEC];
+        loadv<VEC>(x + i * VEC, xv);
+        loadv<VEC>(mean + c, mu);
+        loadv<VEC>(rstd + c, rs);
+        loadv<VEC>(gp, ga);
+        loadv<VEC>(bp, be);
+        if (alpha) loadv<VEC>(alpha + c, al);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float inv = rs[j] * ga[j];                  // tf.nn.batch_normalization: inv = rsqrt(var+eps)*scale
+            float v = xv[j] * inv + (be[j] - mu[j] * inv);    //   x*inv + (offset - mean*inv)
+            out[j] = alpha ? prelu_f(v, al[j]) : v;
+        }
+        if constexpr (VEC == 4)
+            stg4(y + i * 4, make_float4(out[0], out[1], out[2], out[VEC - 1]));
+        else
+            y[i] = out[0];
+    }
+}
+
+struct BnBwdReduceFn {
+    const float *x, *dy, *mean, *rstd, *gamma, *beta, *alpha;
+    int per_sample, HW, C;
+    template <int VEC>
+    __device__ __forceinline__ void operator()(int n, int64_t r, int c, float (&acc)[3][VEC]) const {
+        const int64_t off = ((int64_t)n * HW + r) * C + c;
+        float xv[VEC], dv[VEC], mu[VEC], rs[VEC], ga[VEC], be[VEC], al[VEC];
+        loadv<VEC>(x + off, xv);
+        loadv<VEC>(dy + off, dv);
+        loadv<VEC>(mean + c, mu);
+        loadv<VEC>(rstd + c, rs);
+        loadv<VEC>(gamma + (per_sample ? (int64_t)n * C : 0) + c, ga);
+        loadv<VEC>(beta + (per_sample ? (int64_t)n * C : 0) + c, be);
+        if (alpha) loadv<VEC>(alpha + c, al);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xh = (xv[j] - mu[j]) * rs[j];
+            const float pre = xh * ga[j] + be[j];
+            const float g = alpha ? dv[j] * prelu_d(pre, al[j]) : dv[j];
+            acc[0][j] += g;
+            acc[1][j] += g * xh;
+            acc[2][j] += alpha ? dv[j] * fminf(pre, 0.f) : 0.f;
+        }
+    }
+};
+
+template <int VEC>
+__global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_bwd_dx_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta, int per_sample,
+    const float* __restrict__ alpha, const float* __restrict__ cm, float* __restrict__ dx, int N, int HW, int C) {
+    const int CV = C / VEC;
+    const int64_t total = (int64_t)N * HW * CV;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c = (int)(i % CV) * VEC;
+        const int n = (int)(i / ((int64_t)HW * CV));
+        float xv[VEC], dv[VEC], mu[VEC], rs[VEC], ga[VEC], be[VEC], al[VEC], m1[VEC], m2[VEC], out[VEC];
+        loadv<VEC>(x + i * VEC, xv);
+        loadv<VEC>(dy + i * VEC, dv);
+        loadv<VEC>(mean + c, mu);
+        loadv<VEC>(rstd + c, rs);
+        loadv<VEC>(gamma + (per_sample ? (int64_t)n * C : 0) + c, ga);
+        loadv<VEC>(beta + (per_sample ? (int64_t)n * C : 0) + c, be);
+        loadv<VEC>(cm + c, m1);
+        loadv<VEC>(cm + C + c, m2);
+        if (alpha) loadv<VEC>(alpha + c, al);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xh = (xv[j] - mu[j]) * rs[j];
+            const float pre = xh * ga[j] + be[j];
+            const float g = alpha ? dv[j] * prelu_d(pre, al[j]) : dv[j];
+            out[j] = rs[j] * (g * ga[j] - m1[j] - xh * m2[j]);
+        }
+        if constexpr (VEC == 4)
+            stg4(dx + i * 4, make_float4(out[0], out[1], out[2], out[VEC - 1]));
+        else
+            dx[i] = out[0];
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* part, const float* gamma, int per_sample, double count,
+                                       float* dgamma, float* dbeta, float* dalpha, float* cm, int N, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* p0 = part;
+    const float* p1 = part + (int64_t)N * C;
+    const float* p2 = part + 2 * (int64_t)N * C;
+    double s0 = 0, s1 = 0, s2 = 0, g0 = 0, g1 = 0;
+    for (int n = 0; n < N; ++n) {
+        const float a = p0[(int64_t)n * C + c], b = p1[(int64_t)n * C + c];
+        const float ga = gamma[(per_sample ? (int64_t)n * C : 0) + c];
+        s0 += a;
+        s1 += b;
+        s2 += p2[(int64_t)n * C + c];
+        g0 += (double)ga * a;
+        g1 += (double)ga * b;
+        if (per_sample) {
+            dbeta[(int64_t)n * C + c] = a;
+            dgamma[(int64_t)n * C + c] = b;
+        }
+    }
+    if (!per_sample) {
+        dbeta[c] = (float)s0;
+        dgamma[c] = (float)s1;
+    }
+    if (dalpha) dalpha[c] = (float)s2;
+    // local (per-rank) numerators; caller all-reduces cm for cross-replica BN before the dx pass
+    cm[c] = (float)(g0 / count);
+    cm[C + c] = (float)(g1 / count);
+}
+
+// ------------------------------------------------------------------------------------------
+// stand-alone PReLU
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(EW_BLOCK) void prelu_fwd_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ alpha, float* __restrict__ y,
+                                                              int64_t total_v, int C) {
+    const int CV = C / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total_v; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c = (int)(i % CV) * VEC;
+        float xv[VEC], al[VEC];
+        loadv<VEC>(x + i * VEC, xv);
+        loadv<VEC>(alpha + c, al);
+        if constexpr (VEC == 4)
+            stg4(y + i * 4, make_float4(prelu_f(xv[0], al[0]), prelu_f(xv[1], al[1]), prelu_f(xv[2], al[2]),
+                                        prelu_f(xv[VEC - 1], al[VEC - 1])));
+        else
+            y[i] = prelu_f(xv[0], al[0]);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(EW_BLOCK) void prelu_bwd_dx_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ dy,
+                                                                 const float* __restrict__ alpha,
+                                                                 float* __restrict__ dx, int64_t total_v, int C) {
+    const int CV = C / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total_v; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c = (int)(i % CV) * VEC;
+        float xv[VEC], dv[VEC], al[VEC];
+        loadv<VEC>(x + i * VEC, xv);
+        loadv<VEC>(dy + i * VEC, dv);
+        loadv<VEC>(alpha + c, al);
+        if constexpr (VEC == 4)
+            stg4(dx + i * 4, make_float4(dv[0] * prelu_d(xv[0], al[0]), dv[1] * prelu_d(xv[1], al[1]),
+                                         dv[2] * prelu_d(xv[2], al[2]), dv[VEC - 1] * prelu_d(xv[VEC - 1], al[VEC - 1])));
+        else
+            dx[i] = dv[0] * prelu_d(xv[0], al[0]);
+    }
+}
+
+struct PreluDalphaFn {
+    const float *x, *dy;
+    int C;
+    template <int VEC>
+    __device__ __forceinline__ void operator()(int, int64_t r, int c, float (&acc)[1][VEC]) const {
+        float xv[VEC], dv[VEC];
+        loadv<VEC>(x + r * C + c, xv);
+        loadv<VEC>(dy + r * C + c, dv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[0][j] += dv[j] * fminf(xv[j], 0.f);
+    }
+};
+
+struct BiasGradFn {
+    const float* dy;
+    int C;
+    template <int VEC>
+    __device__ __forceinline__ void operator()(int, int64_t r, int c, float (&acc)[1][VEC]) const {
+        float dv[VEC];
+        loadv<VEC>(dy + r * C + c, dv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[0][j] += dv[j];
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// max pool 2x2 / global sum pool
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(EW_BLOCK) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 int N, int H, int W, int C) {
+    const int CV = C / VEC, Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)N * Ho * Wo * CV;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int cv = (int)(i % CV);
+        int64_t t = i / CV;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const float* p = x + (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + cv * VEC;
+        float a[VEC], b[VEC], c_[VEC], d[VEC], o[VEC];
+        loadv<VEC>(p, a);
+        loadv<VEC>(p + C, b);
+        loadv<VEC>(p + (int64_t)W * C, c_);
+        loadv<VEC>(p + (int64_t)W * C + C, d);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(c_[j], d[j]));
+        if constexpr (VEC == 4)
+            stg4(y + i * 4, make_float4(o[0], o[1], o[2], o[VEC - 1]));
+        else
+            y[i] = o[0];
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(EW_BLOCK) void maxpool2_bwd_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ dy, float* __restrict__ dx,
+                                                                 int N, int H, int W, int C) {
+    const int CV = C / VEC, Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)N * Ho * Wo * CV;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int cv = (int)(i % CV);
+        int64_t t = i / CV;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const int64_t base = (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + cv * VEC;
+        const int64_t o1 = C, o2 = (int64_t)W * C, o3 = (int64_t)W * C + C;
+        float a[VEC], b[VEC], c_[VEC], d[VEC], g[VEC];
+        loadv<VEC>(x + base, a);
+        loadv<VEC>(x + base + o1, b);
+        loadv<VEC>(x + base + o2, c_);
+        loadv<VEC>(x + base + o3, d);
+        loadv<VEC>(dy + i * VEC, g);
+        float ra[VEC], rb[VEC], rc[VEC], rd[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float m = fmaxf(fmaxf(a[j], b[j]), fmaxf(c_[j], d[j]));
+            // first maximum in window order (0,0),(0,1),(1,0),(1,1)
+            const bool sa = a[j] == m;
+            const bool sb = !sa && b[j] == m;
+            const bool sc = !sa && !sb && c_[j] == m;
+            const bool sd = !sa && !sb && !sc;
+            ra[j] = sa ? g[j] : 0.f;
+            rb[j] = sb ? g[j] : 0.f;
+            rc[j] = sc ? g[j] : 0.f;
+            rd[j] = sd ? g[j] : 0.f;
+        }
+        if constexpr (VEC == 4) {
+            stg4(dx + base, make_float4(ra[0], ra[1], ra[2], ra[VEC - 1]));
+            stg4(dx + base + o1, make_float4(rb[0], rb[1], rb[2], rb[VEC - 1]));
+            stg4(dx + base + o2, make_float4(rc[0], rc[1], rc[2], rc[VEC - 1]));
+            stg4(dx + base + o3, make_float4(rd[0], rd[1], rd[2], rd[VEC - 1]));
+        } else {
+            dx[base] = ra[0];
+            dx[base + o1] = rb[0];
+            dx[base + o2] = rc[0];
+            dx[base + o3] = rd[0];
+        }
+    }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void sum_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 int N, int HW, int C) {
+    const int64_t total = (int64_t)N * C;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / C);
+        float s = 0.f;
+        for (int r = 0; r < HW; ++r) s += x[((int64_t)n * HW + r) * C + c];
+        y[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void sum_pool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                 int N, int HW, int C) {
+    const int64_t total = (int64_t)N * HW * C;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / ((int64_t)HW * C));
+        dx[i] = dy[(int64_t)n * C + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// softmax over rows of <= 1024 columns: one wave per row, row held in registers
+// ------------------------------------------------------------------------------------------
+#define SM_MAXPER 16
+__global__ __launch_bounds__(EW_BLOCK) void softmax_fwd_kernel(const float* __restrict__ s, float* __restrict__ p,
+                                                                int64_t rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float* in = s + r * cols;
+        float v[SM_MAXPER];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < SM_MAXPER; ++j) {
+            const int c = lane + 64 * j;
+            v[j] = c < cols ? in[c] : -INFINITY;
+            mx = fmaxf(mx, v[j]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < SM_MAXPER; ++j) {
+            v[j] = (lane + 64 * j) < cols ? __expf(v[j] - mx) : 0.f;
+            sum += v[j];
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        float* o = p + r * cols;
+#pragma unroll
+        for (int j = 0; j < SM_MAXPER; ++j) {
+            const int c = lane + 64 * j;
+            if (c < cols) o[c] = v[j] * inv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void softmax_bwd_kernel(const float* __restrict__ p,
+                                                                const float* __restrict__ dp, float* __restrict__ ds,
+                                                                int64_t rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        float pv[SM_MAXPER], dv[SM_MAXPER];
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < SM_MAXPER; ++j) {
+            const int c = lane + 64 * j;
+            pv[j] = c < cols ? p[r * cols + c] : 0.f;
+            dv[j] = c < cols ? dp[r * cols + c] : 0.f;
+            dot += pv[j] * dv[j];
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int j = 0; j < SM_MAXPER; ++j) {
+            const int c = lane + 64 * j;
+            if (c < cols) ds[r * cols + c] = pv[j] * (dv[j] - dot);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// small elementwise family
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EW_BLOCK) void axpby_kernel(const float* __restrict__ x, float a, float* __restrict__ y,
+                                                          float b, int64_t n) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+        float4 xv = ldg4(x + i * 4), yv;
+        if (b != 0.f) {
+            yv = ldg4(y + i * 4);
+            yv = make_float4(a * xv.x + b * yv.x, a * xv.y + b * yv.y, a * xv.z + b * yv.z, a * xv.w + b * yv.w);
+        } else {
+            yv = make_float4(a * xv.x, a * xv.y, a * xv.z, a * xv.w);
+        }
+        stg4(y + i * 4, yv);
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK)
+        y[i] = b != 0.f ? a * x[i] + b * y[i] : a * x[i];
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void scale_add_kernel(const float* __restrict__ o,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ x, float* __restrict__ y,
+                                                              int64_t n) {
+    const float g = *gamma;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+        float4 ov = ldg4(o + i * 4), xv = ldg4(x + i * 4);
+        stg4(y + i * 4, make_float4(g * ov.x + xv.x, g * ov.y + xv.y, g * ov.z + xv.z, g * ov.w + xv.w));
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK)
+        y[i] = g * o[i] + x[i];
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ sp,
+                                                              float* __restrict__ y, int64_t n) {
+    const float s = *sp;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK)
+        y[i] = s * x[i];
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* out, int64_t n) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+        float4 av = ldg4(a + i * 4), bv = ldg4(b + i * 4);
+        s += av.x * bv.x + av.y * bv.y + av.z * bv.z + av.w * bv.w;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK)
+        s += a[i] * b[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK)
+        y[i] = tanhf(x[i]);
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void tanh_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                             float* __restrict__ dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK)
+        dx[i] = dy[i] * (1.f - y[i] * y[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// spectral norm (ops.py:718-747)
+// scratch layout (floats): [0]=sum v_^2, [1]=sigma, [2]=rs_v, [3]=<G,Wn>; [4 .. 4+rows) = v_ ; then cols of u_raw
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EW_BLOCK) void sn_rowdot_kernel(const float* __restrict__ w,
+                                                              const float* __restrict__ u, float* __restrict__ vraw,
+                                                              float* ssv, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    float ss = 0.f;
+    for (int r = wave; r < rows; r += nwaves) {
+        const float* wr = w + (int64_t)r * cols;
+        float s = 0.f;
+        if ((cols & 3) == 0) {
+            for (int c = lane * 4; c < cols; c += 256) {
+                float4 a = ldg4(wr + c), b = ldg4(u + c);
+                s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            }
+        } else {
+            for (int c = lane; c < cols; c += 64) s += wr[c] * u[c];
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            vraw[r] = s;
+            ss += s * s;
+        }
+    }
+    if (lane == 0 && ss != 0.f) atomicAdd(ssv, ss);
+}
+
+// uraw[c] += sum_{r in chunk} vraw[r] * W[r][c]
+__global__ __launch_bounds__(EW_BLOCK) void sn_colsum_kernel(const float* __restrict__ w,
+                                                              const float* __restrict__ vraw, float* uraw, int rows,
+                                                              int cols, int rows_per_block) {
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(rows, r0 + rows_per_block);
+    const int c = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += vraw[r] * w[(int64_t)r * cols + c];
+    atomicAdd(&uraw[c], s);
+}
+
+// single block: norms, u_out, sigma
+__global__ __launch_bounds__(EW_BLOCK) void sn_finalize_kernel(float* scr, const float* uraw, float* u_out,
+                                                                float* sigma_out, int cols) {
+    __shared__ float sh[4];
+    const float rs_v = rsqrtf(fmaxf(scr[0], 1e-12f));       // l2_normalize(v_)
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < cols; c += EW_BLOCK) {
+        const float t = uraw[c] * rs_v;                     // u_ = v_hat W
+        ss += t * t;
+    }
+    ss = block_sum_256(ss, sh);
+    const float rs_u = rsqrtf(fmaxf(ss, 1e-12f));           // l2_normalize(u_)
+    for (int c = threadIdx.x; c < cols; c += EW_BLOCK) u_out[c] = uraw[c] * rs_v * rs_u;
+    if (threadIdx.x == 0) {
+        const float sigma = ss * rs_u;                      // v_hat W u_hat^T = u_ . u_hat
+        scr[1] = sigma;
+        scr[2] = rs_v;
+        *sigma_out = sigma;
+    }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void sn_normalize_kernel(const float* __restrict__ w, const float* scr,
+                                                                 const float* vraw, float* __restrict__ wn,
+                                                                 float* v_out, int64_t n, int rows) {
+    const float sigma = scr[1];
+    const float rs_v = scr[2];
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+        float4 a = ldg4(w + i * 4);
+        stg4(wn + i * 4, make_float4(a.x / sigma, a.y / sigma, a.z / sigma, a.w / sigma));
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK)
+        wn[i] = w[i] / sigma;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * EW_BLOCK)
+        v_out[i] = vraw[i] * rs_v;
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void sn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ u,
+                                                           const float* __restrict__ v, const float* sigma,
+                                                           const float* dotp, float* __restrict__ dw, int rows,
+                                                           int cols) {
+    const float inv_sigma = 1.f / *sigma;
+    const float d = *dotp;
+    const int64_t n = (int64_t)rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        dw[i] = (g[i] - d * v[r] * u[c]) * inv_sigma;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TF Adam + EMA over a flat arena
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EW_BLOCK) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         float* __restrict__ ema, float lr_t, float b1, float b2,
+                                                         float eps, float decay, float gscale, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float pi = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+        p[i] = pi;
+        if (ema) ema[i] = decay * ema[i] + (1.f - decay) * pi;
+    }
+}
+
+}  // namespace bg
+
+using namespace bg;
+
+extern "C" {
+
+int bg_bn_stats(const float* x, float* sums, int64_t rows, int C, void* stream) {
+    BG_REQUIRE(x && sums && rows > 0 && C > 0, "bg_bn_stats: bad argument");
+    BnStatsFn fn{x, C};
+    launch_colreduce<2>(fn, sums, (int64_t)C, rows, 1, C, as_stream(stream));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_bn_finalize(const float* sums, double count, float eps, float momentum, int unbiased_moving_var, float* mean,
+                   float* rstd, float* moving_mean, float* moving_var, int C, void* stream) {
+    BG_REQUIRE(sums && mean && rstd && C > 0 && count > 0, "bg_bn_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count, eps,
+                       momentum, unbiased_moving_var, mean, rstd, moving_mean, moving_var, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_bn_apply_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        int per_sample, const float* alpha, float* y, int N, int HW, int C, void* stream) {
+    BG_REQUIRE(x && mean && rstd && gamma && beta && y && N > 0 && HW > 0 && C > 0, "bg_bn_apply_act_fwd: bad argument");
+    const int64_t total = (int64_t)N * HW * C;
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((bn_apply_act_fwd_kernel<4>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK), 0, as_stream(stream),
+                           x, mean, rstd, gamma, beta, per_sample, alpha, y, N, HW, C);
+    else
+        hipLaunchKernelGGL((bn_apply_act_fwd_kernel<1>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), x,
+                           mean, rstd, gamma, beta, per_sample, alpha, y, N, HW, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_bn_apply_act_bwd_reduce(const float* x, const float* dy, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, int per_sample, const float* alpha, float* part,
+                               int N, int HW, int C, void* stream) {
+    BG_REQUIRE(x && dy && mean && rstd && gamma && beta && part && N > 0 && HW > 0 && C > 0,
+               "bg_bn_apply_act_bwd_reduce: bad argument");
+    if (hipMemsetAsync(part, 0, sizeof(float) * 3 * (size_t)N * C, as_stream(stream)) != hipSuccess) {
+        set_error("bg_bn_apply_act_bwd_reduce: memset failed");
+        return BG_ERR_LAUNCH;
+    }
+    BnBwdReduceFn fn{x, dy, mean, rstd, gamma, beta, alpha, per_sample, HW, C};
+    launch_colreduce<3>(fn, part, (int64_t)N * C, HW, N, C, as_stream(stream));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_bn_bwd_finalize(const float* part, const float* gamma, int per_sample, double count, float* dgamma, float* dbeta,
+                       float* dalpha, float* cm, int N, int C, void* stream) {
+    BG_REQUIRE(part && gamma && dgamma && dbeta && cm && N > 0 && C > 0 && count > 0, "bg_bn_bwd_finalize: bad argument");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), part, gamma,
+                       per_sample, count, dgamma, dbeta, dalpha, cm, N, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_bn_apply_act_bwd_dx(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, int per_sample, const float* alpha, const float* cm, float* dx, int N,
+                           int HW, int C, void* stream) {
+    BG_REQUIRE(x && dy && mean && rstd && gamma && beta && cm && dx && N > 0 && HW > 0 && C > 0,
+               "bg_bn_apply_act_bwd_dx: bad argument");
+    const int64_t total = (int64_t)N * HW * C;
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((bn_apply_act_bwd_dx_kernel<4>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK), 0,
+                           as_stream(stream), x, dy, mean, rstd, gamma, beta, per_sample, alpha, cm, dx, N, HW, C);
+    else
+        hipLaunchKernelGGL((bn_apply_act_bwd_dx_kernel<1>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
+                           x, dy, mean, rstd, gamma, beta, per_sample, alpha, cm, dx, N, HW, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_prelu_fwd(const float* x, const float* alpha, float* y, int64_t rows, int C, void* stream) {
+    BG_REQUIRE(x && alpha && y && rows > 0 && C > 0, "bg_prelu_fwd: bad argument");
+    const int64_t total = rows * C;
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((prelu_fwd_kernel<4>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK), 0, as_stream(stream), x,
+                           alpha, y, total / 4, C);
+    else
+        hipLaunchKernelGGL((prelu_fwd_kernel<1>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), x, alpha,
+                           y, total, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx, float* dalpha, int64_t rows, int C,
+                 void* stream) {
+    BG_REQUIRE(x && dy && alpha && rows > 0 && C > 0, "bg_prelu_bwd: bad argument");
+    const int64_t total = rows * C;
+    if (dx) {
+        if (C % 4 == 0)
+            hipLaunchKernelGGL((prelu_bwd_dx_kernel<4>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK), 0, as_stream(stream),
+                               x, dy, alpha, dx, total / 4, C);
+        else
+            hipLaunchKernelGGL((prelu_bwd_dx_kernel<1>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), x,
+                               dy, alpha, dx, total, C);
+        BG_LAUNCH_CHECK();
+    }
+    if (dalpha) {
+        PreluDalphaFn fn{x, dy, C};
+        launch_colreduce<1>(fn, dalpha, (int64_t)C, rows, 1, C, as_stream(stream));
+        BG_LAUNCH_CHECK();
+    }
+    return BG_OK;
+}
+
+int bg_bias_grad(const float* dy, float* db, int64_t rows, int C, void* stream) {
+    BG_REQUIRE(dy && db && rows > 0 && C > 0, "bg_bias_grad: bad argument");
+    if (hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, as_stream(stream)) != hipSuccess) {
+        set_error("bg_bias_grad: memset failed");
+        return BG_ERR_LAUNCH;
+    }
+    BiasGradFn fn{dy, C};
+    launch_colreduce<1>(fn, db, (int64_t)C, rows, 1, C, as_stream(stream));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    BG_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, "bg_maxpool2_fwd: bad argument");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((maxpool2_fwd_kernel<4>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK), 0, as_stream(stream), x,
+                           y, N, H, W, C);
+    else
+        hipLaunchKernelGGL((maxpool2_fwd_kernel<1>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), x, y,
+                           N, H, W, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    BG_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0,
+               "bg_maxpool2_bwd: bad argument");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((maxpool2_bwd_kernel<4>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK), 0, as_stream(stream), x,
+                           dy, dx, N, H, W, C);
+    else
+        hipLaunchKernelGGL((maxpool2_bwd_kernel<1>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), x, dy,
+                           dx, N, H, W, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_softmax_fwd(const float* s, float* p, int64_t rows, int cols, void* stream) {
+    BG_REQUIRE(s && p && rows > 0 && cols > 0, "bg_softmax_fwd: bad argument");
+    if (cols > 64 * SM_MAXPER) {
+        set_error("bg_softmax_fwd: cols=%d > %d unsupported", cols, 64 * SM_MAXPER);
+        return BG_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(ew_grid(rows * 64)), dim3(EW_BLOCK), 0, as_stream(stream), s, p, rows,
+                       cols);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, int cols, void* stream) {
+    BG_REQUIRE(p && dp && ds && rows > 0 && cols > 0, "bg_softmax_bwd: bad argument");
+    if (cols > 64 * SM_MAXPER) {
+        set_error("bg_softmax_bwd: cols=%d > %d unsupported", cols, 64 * SM_MAXPER);
+        return BG_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(ew_grid(rows * 64)), dim3(EW_BLOCK), 0, as_stream(stream), p, dp, ds,
+                       rows, cols);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_sum_pool_fwd(const float* x, float* y, int N, int HW, int C, void* stream) {
+    BG_REQUIRE(x && y && N > 0 && HW > 0 && C > 0, "bg_sum_pool_fwd: bad argument");
+    hipLaunchKernelGGL(sum_pool_fwd_kernel, dim3(ew_grid((int64_t)N * C)), dim3(EW_BLOCK), 0, as_stream(stream), x, y,
+                       N, HW, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_sum_pool_bwd(const float* dy, float* dx, int N, int HW, int C, void* stream) {
+    BG_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0, "bg_sum_pool_bwd: bad argument");
+    hipLaunchKernelGGL(sum_pool_bwd_kernel, dim3(ew_grid((int64_t)N * HW * C)), dim3(EW_BLOCK), 0, as_stream(stream),
+                       dy, dx, N, HW, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_axpby(const float* x, float a, float* y, float b, int64_t n, void* stream) {
+    BG_REQUIRE(x && y && n > 0, "bg_axpby: bad argument");
+    BG_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "bg_axpby: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, as_stream(stream), x, a, y, b, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_scale_add(const float* o, const float* gamma_dev, const float* x, float* y, int64_t n, void* stream) {
+    BG_REQUIRE(o && gamma_dev && x && y && n > 0, "bg_scale_add: bad argument");
+    BG_REQUIRE(((uintptr_t)o & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0,
+               "bg_scale_add: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(scale_add_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, as_stream(stream), o, gamma_dev,
+                       x, y, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_dot(const float* a, const float* b, float* out_accum, int64_t n, void* stream) {
+    BG_REQUIRE(a && b && out_accum && n > 0, "bg_dot: bad argument");
+    BG_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0, "bg_dot: pointers must be 16-byte aligned");
+    int grid = ew_grid(n / 4 + 1);
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(dot_kernel, dim3(grid), dim3(EW_BLOCK), 0, as_stream(stream), a, b, out_accum, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_scale_dev(const float* x, const float* s_dev, float* y, int64_t n, void* stream) {
+    BG_REQUIRE(x && s_dev && y && n > 0, "bg_scale_dev: bad argument");
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, as_stream(stream), x, s_dev, y, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_tanh_fwd(const float* x, float* y, int64_t n, void* stream) {
+    BG_REQUIRE(x && y && n > 0, "bg_tanh_fwd: bad argument");
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, as_stream(stream), x, y, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream) {
+    BG_REQUIRE(y && dy && dx && n > 0, "bg_tanh_bwd: bad argument");
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, as_stream(stream), y, dy, dx, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+size_t bg_spectral_norm_workspace_bytes(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return sizeof(float) * (size_t)(4 + rows + cols);
+}
+
+int bg_spectral_norm_fwd(const float* w, const float* u_in, float* u_out, float* v_out, float* sigma_out,
+                         float* w_norm, int rows, int cols, void* ws, size_t ws_bytes, void* stream) {
+    BG_REQUIRE(w && u_in && u_out && v_out && sigma_out && w_norm && rows > 0 && cols > 0,
+               "bg_spectral_norm_fwd: bad argument");
+    BG_REQUIRE(ws && ws_bytes >= bg_spectral_norm_workspace_bytes(rows, cols), "bg_spectral_norm_fwd: workspace too small");
+    BG_REQUIRE(((uintptr_t)w & 15) == 0 && ((uintptr_t)w_norm & 15) == 0 && ((uintptr_t)u_in & 15) == 0,
+               "bg_spectral_norm_fwd: pointers must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    float* scr = reinterpret_cast<float*>(ws);
+    float* vraw = scr + 4;
+    float* uraw = vraw + rows;
+    if (hipMemsetAsync(scr, 0, bg_spectral_norm_workspace_bytes(rows, cols), s) != hipSuccess) {
+        set_error("bg_spectral_norm_fwd: memset failed");
+        return BG_ERR_LAUNCH;
+    }
+    int g1 = (rows + 3) / 4;
+    if (g1 > 1024) g1 = 1024;
+    hipLaunchKernelGGL(sn_rowdot_kernel, dim3(g1), dim3(EW_BLOCK), 0, s, w, u_in, vraw, scr, rows, cols);
+    BG_LAUNCH_CHECK();
+    const int cblocks = (cols + EW_BLOCK - 1) / EW_BLOCK;
+    int rchunks = (512 + cblocks - 1) / cblocks;
+    int rpb = (rows + rchunks - 1) / rchunks;
+    if (rpb < 8) rpb = 8;
+    rchunks = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(sn_colsum_kernel, dim3(cblocks, rchunks), dim3(EW_BLOCK), 0, s, w, vraw, uraw, rows, cols, rpb);
+    BG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sn_finalize_kernel, dim3(1), dim3(EW_BLOCK), 0, s, scr, uraw, u_out, sigma_out, cols);
+    BG_LAUNCH_CHECK();
+    const int64_t n = (int64_t)rows * cols;
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, s, w, scr, vraw, w_norm, v_out,
+                       n, rows);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_spectral_norm_bwd(const float* g_wnorm, const float* w_norm, const float* u_hat, const float* v_hat,
+                         const float* sigma, float* dw, int rows, int cols, void* ws, size_t ws_bytes, void* stream) {
+    BG_REQUIRE(g_wnorm && w_norm && u_hat && v_hat && sigma && dw && rows > 0 && cols > 0,
+               "bg_spectral_norm_bwd: bad argument");
+    BG_REQUIRE(ws && ws_bytes >= 16, "bg_spectral_norm_bwd: workspace too small");
+    BG_REQUIRE(((uintptr_t)g_wnorm & 15) == 0 && ((uintptr_t)w_norm & 15) == 0,
+               "bg_spectral_norm_bwd: pointers must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    float* scr = reinterpret_cast<float*>(ws);
+    if (hipMemsetAsync(scr, 0, 16, s) != hipSuccess) {
+        set_error("bg_spectral_norm_bwd: memset failed");
+        return BG_ERR_LAUNCH;
+    }
+    const int64_t n = (int64_t)rows * cols;
+    int grid = ew_grid(n / 4 + 1);
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(dot_kernel, dim3(grid), dim3(EW_BLOCK), 0, s, g_wnorm, w_norm, scr + 3, n);
+    BG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sn_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, g_wnorm, u_hat, v_hat, sigma, scr + 3, dw,
+                       rows, cols);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_adam_tf_ema_step(float* p, const float* g, float* m, float* v, float* ema, float lr_t, float b1, float b2,
+                        float eps, float ema_decay, float grad_scale, int64_t n, void* stream) {
+    BG_REQUIRE(p && g && m && v && n > 0, "bg_adam_tf_ema_step: bad argument");
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, as_stream(stream), p, g, m, v, ema, lr_t, b1,
+                       b2, eps, ema_decay, grad_scale, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,872 @@
+// igemm.hip - fp32 MFMA implicit-GEMM kernels for conv / transposed conv / dense / attention
+// matmuls (gfx950, v_mfma_f32_32x32x2_f32: exact fp32 FMA chain, 64 FLOP/clk/SIMD).
+//
+// Reference call sites replaced: tf.pad+tf.nn.conv2d (ops.py:82,94-98), tf.nn.conv2d_transpose
+// (ops.py:127-132), tf.matmul (ops.py:163-165, 481, 485; utils.py:198,222) and their gradients.
+//
+// Tiling: 256 threads = 4 waves (64 lanes).  Each wave owns TM x TN MFMA tiles of 32x32; the block
+// tile is (32*TM*WM) x (32*TN*WN); K advances in steps of 16 floats through double-buffered LDS,
+// with the next tile's global loads in flight (held in registers) while the current one is on the
+// matrix pipe.  A tiles are stored K-major in LDS ([k][m], row stride == 2 mod 8) so that both
+// the transposing ds_write_b32 (4 per float4) and the MFMA operand ds_read_b32 (lane = row) are
+// bank-conflict free.
+#include "common.h"
+#include "igemm.h"
+
+namespace bg {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define BKT 16  // K tile (floats)
+
+// ------------------------------------------------------------------------------------------
+// gather index math (shared by NN and TN kernels)
+// ------------------------------------------------------------------------------------------
+struct RowPos {
+    int b, ho, wo;
+    bool valid;
+};
+
+__device__ __forceinline__ RowPos decompose_row(const Gather& g, int m, int M, int ph, int pw) {
+    RowPos r;
+    r.valid = m < M;
+    if (g.plain) {
+        r.b = m;
+        r.ho = 0;
+        r.wo = 0;
+        return r;
+    }
+    int wq = m % g.Wq;
+    int t = m / g.Wq;
+    int hq = t % g.Hq;
+    r.b = t / g.Hq;
+    r.ho = hq * g.pstep + ph;
+    r.wo = wq * g.pstep + pw;
+    return r;
+}
+
+// one axis of a CONV-mode gather: source index or -1
+__device__ __forceinline__ int conv_src(int o, int kk, int stride, int pad, int reflect, int n) {
+    int s = o * stride + kk - pad;
+    if (reflect) {
+        s = s < 0 ? -s : s;
+        s = s >= n ? 2 * (n - 1) - s : s;
+        return s;
+    }
+    return (s >= 0 && s < n) ? s : -1;
+}
+
+// one axis of a TCONV-mode gather: numerator hn = o + pad - kk must be a non-negative multiple of stride
+__device__ __forceinline__ int tconv_src_from_num(int hn, int stride, int n) {
+    if (hn < 0) return -1;
+    int s = hn / stride;
+    if (s * stride != hn) return -1;
+    return s < n ? s : -1;
+}
+
+// mirrored source of a TCONV gather with reflect padding (gradient of tf.pad(REFLECT) folded in):
+// the padded positions that alias output pixel o are  pad - o  (1 <= o <= pad)  and
+// 2*(n_out-1) + pad - o  (n_out-1-pad <= o <= n_out-2).
+__device__ __forceinline__ int tconv_mirror_src(int o, int kk, int stride, int pad, int n_out, int n_src) {
+    int hn;
+    if (o >= 1 && o <= pad)
+        hn = pad - o - kk;
+    else if (o >= n_out - 1 - pad && o <= n_out - 2)
+        hn = 2 * (n_out - 1) + pad - o - kk;
+    else
+        return -1;
+    return tconv_src_from_num(hn, stride, n_src);
+}
+
+// up to 4 source offsets (element offsets into the source tensor, -1 = none) for row r and tap (kh,kw)
+template <bool MIRROR>
+__device__ __forceinline__ void tap_sources(const Gather& g, const RowPos& r, int kh, int kw,
+                                            int64_t (&off)[MIRROR ? 4 : 1]) {
+#pragma unroll
+    for (int i = 0; i < (MIRROR ? 4 : 1); ++i) off[i] = -1;
+    if (!r.valid) return;
+    if (g.plain) {
+        off[0] = (int64_t)r.b * g.ld;
+        return;
+    }
+    int h0, w0, h1 = -1, w1 = -1;
+    if (g.mode == GATHER_CONV) {
+        h0 = conv_src(r.ho, kh, g.stride, g.pad, g.reflect, g.Hs);
+        w0 = conv_src(r.wo, kw, g.stride, g.pad, g.reflect, g.Ws);
+    } else {
+        h0 = tconv_src_from_num(r.ho + g.pad - kh, g.stride, g.Hs);
+        w0 = tconv_src_from_num(r.wo + g.pad - kw, g.stride, g.Ws);
+        if (MIRROR && g.reflect) {
+            h1 = tconv_mirror_src(r.ho, kh, g.stride, g.pad, g.Ho, g.Hs);
+            w1 = tconv_mirror_src(r.wo, kw, g.stride, g.pad, g.Wo, g.Ws);
+        }
+    }
+    const int64_t base = (int64_t)r.b * g.Hs;
+    if (h0 >= 0 && w0 >= 0) off[0] = ((base + h0) * g.Ws + w0) * g.ld;
+    if (MIRROR) {
+        if (h0 >= 0 && w1 >= 0) off[1] = ((base + h0) * g.Ws + w1) * g.ld;
+        if (h1 >= 0 && w0 >= 0) off[2] = ((base + h1) * g.Ws + w0) * g.ld;
+        if (h1 >= 0 && w1 >= 0) off[3] = ((base + h1) * g.Ws + w1) * g.ld;
+    }
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__device__ __forceinline__ float4 load_chan4(const float* base, int64_t off, int c, int C, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (off < 0) return v;
+    const float* p = base + off + c;
+    if (vec) {
+        if (c < C) v = ld4(p);
+    } else {
+        if (c + 0 < C) v.x = p[0];
+        if (c + 1 < C) v.y = p[1];
+        if (c + 2 < C) v.z = p[2];
+        if (c + 3 < C) v.w = p[3];
+    }
+    return v;
+}
+
+__device__ __forceinline__ void add4(float4& a, const float4& b) {
+    a.x += b.x;
+    a.y += b.y;
+    a.z += b.z;
+    a.w += b.w;
+}
+
+// ------------------------------------------------------------------------------------------
+// NN kernel
+// ------------------------------------------------------------------------------------------
+template <int TM, int TN, int WM, int WN, bool BT, bool MIRROR>
+__global__ __launch_bounds__(256) void nn_kernel(const NNParams p) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int LDA = BM + 2;                 // == 2 (mod 8): conflict-free transposing writes
+    constexpr int LDB = BT ? BN + 2 : BN + 4;   // BT: transposing writes ; else 16-byte aligned rows
+    constexpr int AROWS = BM / 64;              // float4 A loads per thread per K tile
+    constexpr int NSRC = MIRROR ? 4 : 1;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) float As[2][BKT * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BKT * LDB];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const Gather& g = p.g;
+    const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const float* Abase = p.A;
+    const float* Bbase = p.B;
+    float* Obase = p.out;
+    int ph = 0, pw = 0;
+    if (p.batch > 1) {
+        Abase += (int64_t)blockIdx.z * p.strideA;
+        Bbase += (int64_t)blockIdx.z * p.strideB;
+        Obase += (int64_t)blockIdx.z * p.strideC;
+    } else if (g.pstep > 1) {
+        ph = blockIdx.z / g.pstep;
+        pw = blockIdx.z % g.pstep;
+    }
+
+    // tap enumeration of this phase
+    int kh0 = 0, kw0 = 0, kstep = 1, nkh = g.k, nkw = g.k;
+    if (g.mode == GATHER_TCONV && g.pstep > 1) {
+        kstep = g.stride;
+        kh0 = (ph + g.pad) % g.stride;
+        kw0 = (pw + g.pad) % g.stride;
+        nkh = (g.k - kh0 + g.stride - 1) / g.stride;
+        nkw = (g.k - kw0 + g.stride - 1) / g.stride;
+    }
+    const int kc = (p.C + BKT - 1) / BKT;
+    const int niter = nkh * nkw * kc;
+
+    // A-load rows of this thread
+    const int a_kq = (t & 3) * 4;
+    RowPos rows[AROWS];
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) rows[i] = decompose_row(g, m0 + (t >> 2) + 64 * i, p.M, ph, pw);
+    int64_t aoff[AROWS][NSRC];
+
+    // load-stream state
+    int l_ih = 0, l_iw = 0, l_ic = 0;
+    float4 ra[AROWS];
+    constexpr int BLOADS = BT ? (BN + 63) / 64 : (BKT * BN / 4 + 255) / 256;
+    float4 rb[BLOADS];
+
+    auto load_tile = [&]() {
+        const int kh = kh0 + l_ih * kstep, kw = kw0 + l_iw * kstep;
+        if (l_ic == 0) {
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) tap_sources<MIRROR>(g, rows[i], kh, kw, aoff[i]);
+        }
+        const int c0 = l_ic * BKT;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            float4 v = load_chan4(Abase, aoff[i][0], c0 + a_kq, p.C, p.a_vec);
+            if (MIRROR) {
+#pragma unroll
+                for (int s = 1; s < NSRC; ++s) add4(v, load_chan4(Abase, aoff[i][s], c0 + a_kq, p.C, p.a_vec));
+            }
+            ra[i] = v;
+        }
+        const float* wt = Bbase + (int64_t)(kh * g.k + kw) * p.tap_stride;
+        if (BT) {
+            // weight is K-contiguous: B[c][n] at wt + c*1 + n*ldn ; float4 along c
+#pragma unroll
+            for (int i = 0; i < BLOADS; ++i) {
+                const int nrel = (t >> 2) + 64 * i;
+                const int n = n0 + nrel;
+                const int c = c0 + a_kq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nrel < BN && n < p.N) {
+                    const float* q = wt + (int64_t)n * p.ldn + c;
+                    if (p.b_vec) {
+                        if (c < p.C) v = ld4(q);
+                    } else {
+                        if (c + 0 < p.C) v.x = q[0];
+                        if (c + 1 < p.C) v.y = q[1];
+                        if (c + 2 < p.C) v.z = q[2];
+                        if (c + 3 < p.C) v.w = q[3];
+                    }
+                }
+                rb[i] = v;
+            }
+        } else {
+            // weight is N-contiguous: B[c][n] at wt + c*ldk + n ; float4 along n
+#pragma unroll
+            for (int i = 0; i < BLOADS; ++i) {
+                const int idx = t + 256 * i;
+                const int kk = idx / (BN / 4), nq = (idx % (BN / 4)) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int c = c0 + kk, n = n0 + nq;
+                if (idx < BKT * BN / 4 && c < p.C) {
+                    const float* q = wt + (int64_t)c * p.ldk + n;
+                    if (p.b_vec) {
+                        if (n < p.N) v = ld4(q);
+                    } else {
+                        if (n + 0 < p.N) v.x = q[0];
+                        if (n + 1 < p.N) v.y = q[1];
+                        if (n + 2 < p.N) v.z = q[2];
+                        if (n + 3 < p.N) v.w = q[3];
+                    }
+                }
+                rb[i] = v;
+            }
+        }
+        // advance the load stream
+        if (++l_ic == kc) {
+            l_ic = 0;
+            if (++l_iw == nkw) {
+                l_iw = 0;
+                ++l_ih;
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* as = As[buf];
+        float* bs = Bs[buf];
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const int r = (t >> 2) + 64 * i;
+            as[(a_kq + 0) * LDA + r] = ra[i].x;
+            as[(a_kq + 1) * LDA + r] = ra[i].y;
+            as[(a_kq + 2) * LDA + r] = ra[i].z;
+            as[(a_kq + 3) * LDA + r] = ra[i].w;
+        }
+        if (BT) {
+#pragma unroll
+            for (int i = 0; i < BLOADS; ++i) {
+                const int n = (t >> 2) + 64 * i;
+                if (n < BN) {
+                    bs[(a_kq + 0) * LDB + n] = rb[i].x;
+                    bs[(a_kq + 1) * LDB + n] = rb[i].y;
+                    bs[(a_kq + 2) * LDB + n] = rb[i].z;
+                    bs[(a_kq + 3) * LDB + n] = rb[i].w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BLOADS; ++i) {
+                const int idx = t + 256 * i;
+                if (idx < BKT * BN / 4) {
+                    const int kk = idx / (BN / 4), nq = (idx % (BN / 4)) * 4;
+                    *reinterpret_cast<float4*>(&bs[kk * LDB + nq]) = rb[i];
+                }
+            }
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+
+    const int a_rd = (lane >> 5) * LDA + wm * 32 * TM + (lane & 31);
+    const int b_rd = (lane >> 5) * LDB + wn * 32 * TN + (lane & 31);
+
+    for (int it = 0; it < niter; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < niter) load_tile();
+        const float* as = As[cur];
+        const float* bs = Bs[cur];
+#pragma unroll
+        for (int kk = 0; kk < BKT / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[a_rd + 2 * kk * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bs[b_rd + 2 * kk * LDB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < niter) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+    const float alpha = p.alpha ? *p.alpha : 1.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= p.M) continue;
+            int64_t ooff;
+            if (g.plain || g.pstep == 1) {
+                ooff = (int64_t)row * p.out_ld;
+            } else {
+                RowPos rp = decompose_row(g, row, p.M, ph, pw);
+                ooff = (((int64_t)rp.b * g.Ho + rp.ho) * g.Wo + rp.wo) * p.out_ld;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * 32 * TN + 32 * j + (lane & 31);
+                if (col < p.N) {
+                    float v = acc[i][j][r] * alpha;
+                    if (p.bias) v += p.bias[col];
+                    float* o = Obase + ooff + col;
+                    if (p.accumulate) v += *o;
+                    *o = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN kernel: out[tap][ca][cb] = sum_rows A(row, tap)[ca] * Bv(row)[cb]
+// ------------------------------------------------------------------------------------------
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void tn_kernel(const TNParams p) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int ALOADS = (BKT * BM / 4 + 255) / 256;
+    constexpr int BLOADS = (BKT * BN / 4 + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) float As[2][BKT * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BKT * LDB];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const Gather& g = p.g;
+
+    const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+    const int ca0 = tile_m * BM, cb0 = tile_n * BN;
+    const int tap = blockIdx.y;
+    const int kh = tap / g.k, kw = tap % g.k;
+    const int zb = blockIdx.z / p.splitk, zs = blockIdx.z % p.splitk;
+
+    const float* Abase = p.A + (int64_t)zb * p.strideA;
+    const float* Bbase = p.Bv + (int64_t)zb * p.strideB;
+
+    const int row_begin = zs * p.rows_per_split;
+    const int row_end = min(p.M, row_begin + p.rows_per_split);
+    const int niter = (row_end - row_begin + BKT - 1) / BKT;
+
+    float4 ra[ALOADS], rb[BLOADS];
+    int l_row = row_begin;
+
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < ALOADS; ++i) {
+            const int idx = t + 256 * i;
+            const int kr = idx / (BM / 4), cq = (idx % (BM / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int m = l_row + kr;
+            if (idx < BKT * BM / 4 && m < row_end) {
+                RowPos rp = decompose_row(g, m, p.M, 0, 0);
+                int64_t off[1];
+                tap_sources<false>(g, rp, kh, kw, off);
+                v = load_chan4(Abase, off[0], ca0 + cq, p.Ca, p.a_vec);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BLOADS; ++i) {
+            const int idx = t + 256 * i;
+            const int kr = idx / (BN / 4), cq = (idx % (BN / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int m = l_row + kr;
+            if (idx < BKT * BN / 4 && m < row_end)
+                v = load_chan4(Bbase, (int64_t)m * p.b_ld, cb0 + cq, p.Cb, p.b_vec);
+            rb[i] = v;
+        }
+        l_row += BKT;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < ALOADS; ++i) {
+            const int idx = t + 256 * i;
+            if (idx < BKT * BM / 4) {
+                const int kr = idx / (BM / 4), cq = (idx % (BM / 4)) * 4;
+                *reinterpret_cast<float4*>(&As[buf][kr * LDA + cq]) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BLOADS; ++i) {
+            const int idx = t + 256 * i;
+            if (idx < BKT * BN / 4) {
+                const int kr = idx / (BN / 4), cq = (idx % (BN / 4)) * 4;
+                *reinterpret_cast<float4*>(&Bs[buf][kr * LDB + cq]) = rb[i];
+            }
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (niter > 0) {
+        load_tile();
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int a_rd = (lane >> 5) * LDA + wm * 32 * TM + (lane & 31);
+    const int b_rd = (lane >> 5) * LDB + wn * 32 * TN + (lane & 31);
+
+    for (int it = 0; it < niter; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < niter) load_tile();
+        const float* as = As[cur];
+        const float* bs = Bs[cur];
+#pragma unroll
+        for (int kk = 0; kk < BKT / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[a_rd + 2 * kk * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bs[b_rd + 2 * kk * LDB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < niter) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    const float alpha = p.alpha ? *p.alpha : 1.0f;
+    float* obase = p.out + (int64_t)zb * p.strideC + (int64_t)zs * p.slab_stride + (int64_t)tap * p.out_tap_stride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = ca0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= p.Ca) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = cb0 + wn * 32 * TN + 32 * j + (lane & 31);
+                if (col < p.Cb) obase[(int64_t)row * p.out_ld + col] = acc[i][j][r] * alpha;
+            }
+        }
+    }
+}
+
+// sum split-K slabs: out[i] = sum_z ws[z*slab + i]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                          int64_t n, int splitk, int64_t slab) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < splitk; ++z) s += ws[(int64_t)z * slab + i];
+        out[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int TM, int TN, int WM, int WN>
+static void launch_nn_cfg(const NNParams& p0, bool bt, bool mirror, int zdim, hipStream_t s) {
+    NNParams p = p0;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    dim3 grid(tiles_m * p.tiles_n, 1, zdim);
+    if (bt) {
+        if (mirror)
+            hipLaunchKernelGGL((nn_kernel<TM, TN, WM, WN, true, true>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((nn_kernel<TM, TN, WM, WN, true, false>), grid, dim3(256), 0, s, p);
+    } else {
+        if (mirror)
+            hipLaunchKernelGGL((nn_kernel<TM, TN, WM, WN, false, true>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((nn_kernel<TM, TN, WM, WN, false, false>), grid, dim3(256), 0, s, p);
+    }
+}
+
+// tile choice: largest tile that still yields >= ~1.5 waves of blocks over the 256 CUs
+static int launch_nn(NNParams& p, bool bt, bool mirror, int zdim, hipStream_t s) {
+    auto blocks = [&](int bm, int bn) {
+        return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * zdim;
+    };
+    const int64_t want = 384;
+    if (p.N <= 32) {
+        launch_nn_cfg<1, 1, 4, 1>(p, bt, mirror, zdim, s);        // 128 x 32
+    } else if (p.N <= 64) {
+        if (blocks(128, 64) >= want)
+            launch_nn_cfg<2, 1, 2, 2>(p, bt, mirror, zdim, s);    // 128 x 64
+        else
+            launch_nn_cfg<1, 1, 2, 2>(p, bt, mirror, zdim, s);    // 64 x 64
+    } else {
+        if (blocks(128, 128) >= want)
+            launch_nn_cfg<2, 2, 2, 2>(p, bt, mirror, zdim, s);    // 128 x 128
+        else if (blocks(128, 64) >= want)
+            launch_nn_cfg<2, 1, 2, 2>(p, bt, mirror, zdim, s);    // 128 x 64
+        else
+            launch_nn_cfg<1, 1, 2, 2>(p, bt, mirror, zdim, s);    // 64 x 64
+    }
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+template <int TM, int TN, int WM, int WN>
+static void launch_tn_cfg(const TNParams& p0, int taps, hipStream_t s) {
+    TNParams p = p0;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    const int tiles_m = (p.Ca + BM - 1) / BM;
+    p.tiles_n = (p.Cb + BN - 1) / BN;
+    dim3 grid(tiles_m * p.tiles_n, taps, p.batch * p.splitk);
+    hipLaunchKernelGGL((tn_kernel<TM, TN, WM, WN>), grid, dim3(256), 0, s, p);
+}
+
+struct TNPlan {
+    int bm, bn, splitk, rows_per_split;
+};
+
+static TNPlan plan_tn(int Ca, int Cb, int taps, int batch, int M) {
+    TNPlan pl;
+    // available tiles: (128,128) (128,64) (64,64) (128,32)
+    if (Cb <= 32) { pl.bm = 128; pl.bn = 32; }
+    else if (Cb <= 64) { pl.bn = 64; pl.bm = Ca <= 64 ? 64 : 128; }
+    else if (Ca <= 64) { pl.bm = 64; pl.bn = 64; }
+    else { pl.bm = 128; pl.bn = 128; }
+    const int64_t tiles = (int64_t)((Ca + pl.bm - 1) / pl.bm) * ((Cb + pl.bn - 1) / pl.bn) * taps * batch;
+    int64_t want = 512;
+    int sk = (int)((want + tiles - 1) / tiles);
+    const int max_sk = (M + 4 * BKT - 1) / (4 * BKT);      // at least 64 rows per split
+    if (sk > max_sk) sk = max_sk;
+    if (sk < 1) sk = 1;
+    if (sk > 256) sk = 256;
+    int rps = (M + sk - 1) / sk;
+    rps = (rps + BKT - 1) / BKT * BKT;
+    sk = (M + rps - 1) / rps;
+    pl.splitk = sk;
+    pl.rows_per_split = rps;
+    return pl;
+}
+
+static size_t tn_workspace_bytes(int Ca, int Cb, int taps, int batch, int M) {
+    TNPlan pl = plan_tn(Ca, Cb, taps, batch, M);
+    if (pl.splitk <= 1) return 0;
+    return (size_t)pl.splitk * taps * Ca * Cb * batch * sizeof(float);
+}
+
+// out layout contiguous [batch][taps][Ca][Cb] required when split-K is used
+static int launch_tn(TNParams& p, int taps, float* final_out, void* ws, size_t ws_bytes, hipStream_t s) {
+    TNPlan pl = plan_tn(p.Ca, p.Cb, taps, p.batch, p.M);
+    const int64_t total = (int64_t)p.batch * taps * p.Ca * p.Cb;
+    const bool contiguous = (p.out_ld == p.Cb) && (p.out_tap_stride == (int64_t)p.Ca * p.Cb) &&
+                            (p.batch == 1 || p.strideC == (int64_t)taps * p.Ca * p.Cb);
+    if (pl.splitk > 1 && (!contiguous || ws == nullptr || ws_bytes < (size_t)pl.splitk * total * sizeof(float))) {
+        pl.splitk = 1;
+        pl.rows_per_split = (p.M + BKT - 1) / BKT * BKT;
+    }
+    p.splitk = pl.splitk;
+    p.rows_per_split = pl.rows_per_split;
+    if (pl.splitk > 1) {
+        p.out = reinterpret_cast<float*>(ws);
+        p.slab_stride = total;
+    } else {
+        p.out = final_out;
+        p.slab_stride = 0;
+    }
+    if (pl.bm == 128 && pl.bn == 128)
+        launch_tn_cfg<2, 2, 2, 2>(p, taps, s);
+    else if (pl.bm == 128 && pl.bn == 64)
+        launch_tn_cfg<2, 1, 2, 2>(p, taps, s);
+    else if (pl.bm == 64 && pl.bn == 64)
+        launch_tn_cfg<1, 1, 2, 2>(p, taps, s);
+    else
+        launch_tn_cfg<1, 1, 4, 1>(p, taps, s);     // 128 x 32
+    BG_LAUNCH_CHECK();
+    if (pl.splitk > 1) {
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(ws),
+                           final_out, total, pl.splitk, total);
+        BG_LAUNCH_CHECK();
+    }
+    return BG_OK;
+}
+
+static int check_desc(const BgConvDesc* d) {
+    BG_REQUIRE(d != nullptr, "null BgConvDesc");
+    BG_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0,
+               "BgConvDesc: non-positive dimension");
+    BG_REQUIRE(d->k >= 1 && d->k <= 7 && d->stride >= 1 && d->stride <= 2, "BgConvDesc: k=%d stride=%d unsupported",
+               d->k, d->stride);
+    BG_REQUIRE(d->pad_mode == BG_PAD_REFLECT || d->pad_mode == BG_PAD_ZERO, "BgConvDesc: bad pad_mode");
+    BG_REQUIRE(d->pad_lo >= 0 && d->pad_lo < d->k, "BgConvDesc: bad pad_lo");
+    BG_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (1ll << 31) && (int64_t)d->N * d->H * d->W < (1ll << 31),
+               "BgConvDesc: more than 2^31 pixels");
+    return BG_OK;
+}
+
+static int check_conv(const BgConvDesc* d) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    BG_REQUIRE(d->pad_mode == BG_PAD_ZERO || d->pad_lo < d->H, "reflect padding wider than the image");
+    // every output window must start inside the (low-)padded image
+    BG_REQUIRE((d->Ho - 1) * d->stride - d->pad_lo < d->H && (d->Wo - 1) * d->stride - d->pad_lo < d->W,
+               "conv output extent inconsistent with input");
+    if (d->pad_mode == BG_PAD_REFLECT) {
+        // highest padded index read must reflect into range
+        const int hi_h = (d->Ho - 1) * d->stride + d->k - 1 - d->pad_lo;
+        const int hi_w = (d->Wo - 1) * d->stride + d->k - 1 - d->pad_lo;
+        BG_REQUIRE(hi_h <= 2 * (d->H - 1) && hi_w <= 2 * (d->W - 1), "reflect padding out of range");
+    }
+    return BG_OK;
+}
+
+static int check_deconv(const BgConvDesc* d) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    BG_REQUIRE(d->Ho == d->H * d->stride && d->Wo == d->W * d->stride, "deconv: Ho must equal stride*H (SAME)");
+    BG_REQUIRE(d->pad_mode == BG_PAD_ZERO, "deconv: zero padding only");
+    return BG_OK;
+}
+
+static double conv_flops(const BgConvDesc* d, bool deconv) {
+    const double px = deconv ? (double)d->N * d->H * d->W : (double)d->N * d->Ho * d->Wo;
+    return 2.0 * px * d->k * d->k * d->Cin * d->Cout;
+}
+
+}  // namespace bg
+
+using namespace bg;
+
+extern "C" {
+
+int bg_conv2d_fwd(const BgConvDesc* d, const float* x, const float* w, const float* bias, const float* alpha_dev,
+                  float* y, int accumulate, void* stream) {
+    int rc = check_conv(d);
+    if (rc) return rc;
+    NNParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = x; p.B = w; p.bias = bias; p.alpha = alpha_dev; p.out = y;
+    Gather& g = p.g;
+    g.Nb = d->N; g.Hs = d->H; g.Ws = d->W; g.Ho = d->Ho; g.Wo = d->Wo; g.Hq = d->Ho; g.Wq = d->Wo; g.pstep = 1;
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.mode = GATHER_CONV;
+    g.reflect = d->pad_mode == BG_PAD_REFLECT; g.plain = 0; g.ld = d->Cin;
+    p.C = d->Cin; p.M = d->N * d->Ho * d->Wo; p.N = d->Cout;
+    p.tap_stride = (int64_t)d->Cin * d->Cout; p.ldk = d->Cout; p.ldn = 1;
+    p.out_ld = d->Cout; p.accumulate = accumulate; p.batch = 1;
+    p.a_vec = (d->Cin % 4 == 0) && aligned16(x);
+    p.b_vec = (d->Cout % 4 == 0) && aligned16(w);
+    ProfScope prof(as_stream(stream), conv_flops(d, false));
+    return launch_nn(p, false, false, 1, as_stream(stream));
+}
+
+int bg_conv2d_dgrad(const BgConvDesc* d, const float* dy, const float* w, const float* alpha_dev, float* dx,
+                    int accumulate, void* stream) {
+    int rc = check_conv(d);
+    if (rc) return rc;
+    BG_REQUIRE(d->H % d->stride == 0 && d->W % d->stride == 0, "conv dgrad: H,W must be multiples of stride");
+    NNParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = dy; p.B = w; p.bias = nullptr; p.alpha = alpha_dev; p.out = dx;
+    Gather& g = p.g;
+    g.Nb = d->N; g.Hs = d->Ho; g.Ws = d->Wo; g.Ho = d->H; g.Wo = d->W;
+    g.pstep = d->stride; g.Hq = d->H / d->stride; g.Wq = d->W / d->stride;
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.mode = GATHER_TCONV;
+    g.reflect = (d->pad_mode == BG_PAD_REFLECT) && d->pad_lo > 0; g.plain = 0; g.ld = d->Cout;
+    p.C = d->Cout; p.M = d->N * g.Hq * g.Wq; p.N = d->Cin;
+    p.tap_stride = (int64_t)d->Cin * d->Cout; p.ldk = 1; p.ldn = d->Cout;   // B[c=co][n=ci] = w[tap][ci][co]
+    p.out_ld = d->Cin; p.accumulate = accumulate; p.batch = 1;
+    p.a_vec = (d->Cout % 4 == 0) && aligned16(dy);
+    p.b_vec = (d->Cout % 4 == 0) && aligned16(w);
+    ProfScope prof(as_stream(stream), conv_flops(d, false));
+    return launch_nn(p, true, g.reflect != 0, d->stride * d->stride, as_stream(stream));
+}
+
+size_t bg_conv2d_wgrad_workspace_bytes(const BgConvDesc* d) {
+    if (!d) return 0;
+    return tn_workspace_bytes(d->Cin, d->Cout, d->k * d->k, 1, d->N * d->Ho * d->Wo);
+}
+
+int bg_conv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
+                    void* stream) {
+    int rc = check_conv(d);
+    if (rc) return rc;
+    TNParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = x; p.Bv = dy;
+    Gather& g = p.g;
+    g.Nb = d->N; g.Hs = d->H; g.Ws = d->W; g.Ho = d->Ho; g.Wo = d->Wo; g.Hq = d->Ho; g.Wq = d->Wo; g.pstep = 1;
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.mode = GATHER_CONV;
+    g.reflect = d->pad_mode == BG_PAD_REFLECT; g.plain = 0; g.ld = d->Cin;
+    p.Ca = d->Cin; p.Cb = d->Cout; p.b_ld = d->Cout; p.M = d->N * d->Ho * d->Wo;
+    p.out_ld = d->Cout; p.out_tap_stride = (int64_t)d->Cin * d->Cout; p.batch = 1;
+    p.a_vec = (d->Cin % 4 == 0) && aligned16(x);
+    p.b_vec = (d->Cout % 4 == 0) && aligned16(dy);
+    ProfScope prof(as_stream(stream), conv_flops(d, false));
+    return launch_tn(p, d->k * d->k, dw, ws, ws_bytes, as_stream(stream));
+}
+
+int bg_deconv2d_fwd(const BgConvDesc* d, const float* x, const float* w, const float* bias, const float* alpha_dev,
+                    float* y, int accumulate, void* stream) {
+    int rc = check_deconv(d);
+    if (rc) return rc;
+    NNParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = x; p.B = w; p.bias = bias; p.alpha = alpha_dev; p.out = y;
+    Gather& g = p.g;
+    g.Nb = d->N; g.Hs = d->H; g.Ws = d->W; g.Ho = d->Ho; g.Wo = d->Wo;
+    g.pstep = d->stride; g.Hq = d->Ho / d->stride; g.Wq = d->Wo / d->stride;
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.mode = GATHER_TCONV; g.reflect = 0; g.plain = 0;
+    g.ld = d->Cin;
+    p.C = d->Cin; p.M = d->N * g.Hq * g.Wq; p.N = d->Cout;
+    p.tap_stride = (int64_t)d->Cin * d->Cout; p.ldk = 1; p.ldn = d->Cin;    // B[c=ci][n=co] = w[tap][co][ci]
+    p.out_ld = d->Cout; p.accumulate = accumulate; p.batch = 1;
+    p.a_vec = (d->Cin % 4 == 0) && aligned16(x);
+    p.b_vec = (d->Cin % 4 == 0) && aligned16(w);
+    ProfScope prof(as_stream(stream), conv_flops(d, true));
+    return launch_nn(p, true, false, d->stride * d->stride, as_stream(stream));
+}
+
+int bg_deconv2d_dgrad(const BgConvDesc* d, const float* dy, const float* w, const float* alpha_dev, float* dx,
+                      int accumulate, void* stream) {
+    int rc = check_deconv(d);
+    if (rc) return rc;
+    NNParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = dy; p.B = w; p.bias = nullptr; p.alpha = alpha_dev; p.out = dx;
+    Gather& g = p.g;
+    g.Nb = d->N; g.Hs = d->Ho; g.Ws = d->Wo; g.Ho = d->H; g.Wo = d->W; g.Hq = d->H; g.Wq = d->W; g.pstep = 1;
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.mode = GATHER_CONV; g.reflect = 0; g.plain = 0;
+    g.ld = d->Cout;
+    p.C = d->Cout; p.M = d->N * d->H * d->W; p.N = d->Cin;
+    p.tap_stride = (int64_t)d->Cin * d->Cout; p.ldk = d->Cin; p.ldn = 1;    // B[c=co][n=ci] = w[tap][co][ci]
+    p.out_ld = d->Cin; p.accumulate = accumulate; p.batch = 1;
+    p.a_vec = (d->Cout % 4 == 0) && aligned16(dy);
+    p.b_vec = (d->Cin % 4 == 0) && aligned16(w);
+    ProfScope prof(as_stream(stream), conv_flops(d, true));
+    return launch_nn(p, false, false, 1, as_stream(stream));
+}
+
+size_t bg_deconv2d_wgrad_workspace_bytes(const BgConvDesc* d) {
+    if (!d) return 0;
+    return tn_workspace_bytes(d->Cout, d->Cin, d->k * d->k, 1, d->N * d->H * d->W);
+}
+
+int bg_deconv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
+                      void* stream) {
+    int rc = check_deconv(d);
+    if (rc) return rc;
+    // dw[kh,kw,co,ci] = sum_{b,hi,wi} dy[b, hi*s+kh-pad, wi*s+kw-pad, co] * x[b,hi,wi,ci]
+    TNParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = dy; p.Bv = x;
+    Gather& g = p.g;
+    g.Nb = d->N; g.Hs = d->Ho; g.Ws = d->Wo; g.Ho = d->H; g.Wo = d->W; g.Hq = d->H; g.Wq = d->W; g.pstep = 1;
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.mode = GATHER_CONV; g.reflect = 0; g.plain = 0;
+    g.ld = d->Cout;
+    p.Ca = d->Cout; p.Cb = d->Cin; p.b_ld = d->Cin; p.M = d->N * d->H * d->W;
+    p.out_ld = d->Cin; p.out_tap_stride = (int64_t)d->Cin * d->Cout; p.batch = 1;
+    p.a_vec = (d->Cout % 4 == 0) && aligned16(dy);
+    p.b_vec = (d->Cin % 4 == 0) && aligned16(x);
+    ProfScope prof(as_stream(stream), conv_flops(d, true));
+    return launch_tn(p, d->k * d->k, dw, ws, ws_bytes, as_stream(stream));
+}
+
+size_t bg_gemm_workspace_bytes(const BgGemmDesc* d) {
+    if (!d || !d->transA) return 0;
+    return tn_workspace_bytes(d->M, d->N, 1, d->batch > 0 ? d->batch : 1, d->K);
+}
+
+int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bias, const float* alpha_dev,
+            float* C, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    BG_REQUIRE(d != nullptr, "null BgGemmDesc");
+    BG_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch >= 1, "BgGemmDesc: non-positive dimension");
+    const double flops = 2.0 * d->M * d->N * d->K * d->batch;
+    if (!d->transA) {
+        NNParams p;
+        memset(&p, 0, sizeof(p));
+        p.A = A; p.B = B; p.bias = bias; p.alpha = alpha_dev; p.out = C;
+        Gather& g = p.g;
+        g.Nb = d->M; g.Hs = 1; g.Ws = 1; g.Ho = 1; g.Wo = 1; g.Hq = 1; g.Wq = 1; g.pstep = 1;
+        g.k = 1; g.stride = 1; g.pad = 0; g.mode = GATHER_CONV; g.reflect = 0; g.plain = 1; g.ld = d->lda;
+        p.C = d->K; p.M = d->M; p.N = d->N; p.tap_stride = 0;
+        if (d->transB) { p.ldk = 1; p.ldn = d->ldb; } else { p.ldk = d->ldb; p.ldn = 1; }
+        p.out_ld = d->ldc; p.accumulate = accumulate; p.batch = d->batch;
+        p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC;
+        p.a_vec = (d->K % 4 == 0) && (d->lda % 4 == 0) && (d->strideA % 4 == 0) && aligned16(A);
+        if (d->transB)
+            p.b_vec = (d->K % 4 == 0) && (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
+        else
+            p.b_vec = (d->N % 4 == 0) && (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
+        ProfScope prof(as_stream(stream), flops);
+        return launch_nn(p, d->transB != 0, false, d->batch, as_stream(stream));
+    }
+    BG_REQUIRE(!d->transB, "bg_gemm: transA && transB unsupported");
+    BG_REQUIRE(bias == nullptr && !accumulate, "bg_gemm: transA path has no bias / accumulate");
+    TNParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.Bv = B; p.alpha = alpha_dev;
+    Gather& g = p.g;
+    g.Nb = d->K; g.Hs = 1; g.Ws = 1; g.Ho = 1; g.Wo = 1; g.Hq = 1; g.Wq = 1; g.pstep = 1;
+    g.k = 1; g.stride = 1; g.pad = 0; g.mode = GATHER_CONV; g.reflect = 0; g.plain = 1; g.ld = d->lda;
+    p.Ca = d->M; p.Cb = d->N; p.b_ld = d->ldb; p.M = d->K;
+    p.out_ld = d->ldc; p.out_tap_stride = 0; p.batch = d->batch;
+    p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC;
+    p.a_vec = (d->M % 4 == 0) && (d->lda % 4 == 0) && (d->strideA % 4 == 0) && aligned16(A);
+    p.b_vec = (d->N % 4 == 0) && (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
+    // out_tap_stride must describe a contiguous [Ca][Cb] tile for the split-K path
+    p.out_tap_stride = (int64_t)d->M * d->N;
+    ProfScope prof(as_stream(stream), flops);
+    return launch_tn(p, 1, C, ws, ws_bytes, as_stream(stream));
+}
+
+}  // extern "C"

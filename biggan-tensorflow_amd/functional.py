@@ -1,0 +1,653 @@
+"""torch.autograd.Function wrappers around the C-ABI kernels (``hip.py``).
+
+PyTorch provides tensor storage, the stream and the backward-graph plumbing; every arithmetic
+operation is a libbiggan_hip.so launch on the current stream.  Gradients of store variables are
+written straight into their slice of the flat gradient arena (``scope.Arena``) instead of
+``Tensor.grad``: the first write of a step overwrites, later ones accumulate.
+"""
+import torch
+from torch.autograd import Function
+
+from . import hip
+from .hip import f32, i32, stream, check, lib, workspace
+
+
+# ------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def axpby(x, a, y, b):
+    """y = a*x + b*y (in place on y)."""
+    check(lib().bg_axpby(f32(x), float(a), f32(y), float(b), x.numel(), stream()))
+    return y
+
+
+def is_variable(t):
+    return getattr(t, "bg_name", None) is not None
+
+
+def emit_grad(var, producer):
+    """Deliver d(loss)/d(var).  ``producer(out)`` must WRITE the gradient into ``out``."""
+    slot = getattr(var, "bg_grad", None)
+    if slot is None:                       # stand-alone variable (not packed into an arena)
+        g = torch.empty(var.shape, dtype=torch.float32, device=var.device)
+        producer(g)
+        if var.grad is None:
+            var.grad = g
+        else:
+            axpby(g, 1.0, var.grad, 1.0)
+        return
+    if not var.bg_touched:
+        producer(slot)
+        var.bg_touched = True
+    else:
+        tmp = torch.empty_like(slot)
+        producer(tmp)
+        axpby(tmp, 1.0, slot, 1.0)
+
+
+def param_grad(t, needed, producer):
+    """Gradient for an input that may be a store variable (side-effect delivery, returns None)
+    or an ordinary autograd tensor (returned)."""
+    if not needed:
+        return None
+    if is_variable(t):
+        emit_grad(t, producer)
+        return None
+    g = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    producer(g)
+    return g
+
+
+def _bias_grad(dy2d, out):
+    check(lib().bg_bias_grad(f32(dy2d), f32(out), dy2d.shape[0], dy2d.shape[1], stream()))
+
+
+# ------------------------------------------------------------------------------------------
+# conv / transposed conv
+# ------------------------------------------------------------------------------------------
+class Conv2dFn(Function):
+    """tf.pad(REFLECT)+tf.nn.conv2d(VALID)+bias_add (ops.py:82,94-98) / zero 'SAME'."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad_lo, Ho, Wo, pad_mode):
+        x = _c(x)
+        w = _c(w)
+        N, H, W_, Cin = x.shape
+        k, _, cin2, Cout = w.shape
+        assert cin2 == Cin, (x.shape, w.shape)
+        d = hip.conv_desc(N, H, W_, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode)
+        y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+        check(lib().bg_conv2d_fwd(d, f32(x), f32(w), f32(bias), None, f32(y), 0, stream()))
+        ctx.desc = d
+        ctx.x, ctx.w, ctx.bias = x, w, bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        d, x, w, bias = ctx.desc, ctx.x, ctx.w, ctx.bias
+        L = lib()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(L.bg_conv2d_dgrad(d, f32(dy), f32(w), None, f32(dx), 0, stream()))
+
+        def wg(out):
+            nb = L.bg_conv2d_wgrad_workspace_bytes(d)
+            ws = workspace(nb, x.device)
+            check(L.bg_conv2d_wgrad(d, f32(x), f32(dy), f32(out), f32(ws), nb, stream()))
+        dw = param_grad(w, ctx.needs_input_grad[1], wg)
+        db = None
+        if bias is not None:
+            db = param_grad(bias, ctx.needs_input_grad[2], lambda out: _bias_grad(dy.view(-1, d.Cout), out))
+        ctx.x = ctx.w = ctx.bias = None
+        return dx, dw, db, None, None, None, None, None
+
+
+class Deconv2dFn(Function):
+    """tf.nn.conv2d_transpose(SAME)+bias_add (ops.py:127-132); w is [k,k,Cout,Cin]."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad_lo, accumulate_into):
+        x = _c(x)
+        w = _c(w)
+        N, H, W_, Cin = x.shape
+        k, _, Cout, cin2 = w.shape
+        assert cin2 == Cin, (x.shape, w.shape)
+        d = hip.conv_desc(N, H, W_, Cin, H * stride, W_ * stride, Cout, k, stride, pad_lo, hip.PAD_ZERO)
+        if accumulate_into is not None:
+            y = accumulate_into          # residual sum fused into the epilogue: y += deconv(x)
+            ctx.mark_dirty(y)
+            acc = 1
+        else:
+            y = torch.empty((N, H * stride, W_ * stride, Cout), dtype=torch.float32, device=x.device)
+            acc = 0
+        check(lib().bg_deconv2d_fwd(d, f32(x), f32(w), f32(bias), None, f32(y), acc, stream()))
+        ctx.desc = d
+        ctx.x, ctx.w, ctx.bias = x, w, bias
+        ctx.acc = acc
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        d, x, w, bias = ctx.desc, ctx.x, ctx.w, ctx.bias
+        L = lib()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(L.bg_deconv2d_dgrad(d, f32(dy), f32(w), None, f32(dx), 0, stream()))
+
+        def wg(out):
+            nb = L.bg_deconv2d_wgrad_workspace_bytes(d)
+            ws = workspace(nb, x.device)
+            check(L.bg_deconv2d_wgrad(d, f32(x), f32(dy), f32(out), f32(ws), nb, stream()))
+        dw = param_grad(w, ctx.needs_input_grad[1], wg)
+        db = None
+        if bias is not None:
+            db = param_grad(bias, ctx.needs_input_grad[2], lambda out: _bias_grad(dy.view(-1, d.Cout), out))
+        ctx.x = ctx.w = ctx.bias = None
+        dacc = dy if ctx.acc else None
+        return dx, dw, db, None, None, dacc
+
+
+# ------------------------------------------------------------------------------------------
+# matmul family
+# ------------------------------------------------------------------------------------------
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=1, sA=0, sB=0, sC=0,
+         bias=None, alpha_dev=None, accumulate=False):
+    """Raw bg_gemm launch on preallocated tensors (row-major, explicit leading dimensions)."""
+    d = hip.BgGemmDesc(M, N, K, int(transA), int(transB), lda, ldb, ldc, batch, sA, sB, sC)
+    L = lib()
+    nb = L.bg_gemm_workspace_bytes(d)
+    ws = workspace(nb, C.device) if nb else None
+    check(L.bg_gemm(d, f32(A) if A.is_contiguous() else hip.c_void_p(A.data_ptr()),
+                    f32(B) if B.is_contiguous() else hip.c_void_p(B.data_ptr()),
+                    f32(bias), f32(alpha_dev), f32(C), int(accumulate), f32(ws) if ws is not None else None,
+                    nb, stream()))
+    return C
+
+
+def _row_view(t):
+    """[rows, cols] view with unit column stride -> (tensor, ld).  Column slices are used in place."""
+    assert t.dim() == 2 and t.stride(1) == 1 and t.is_cuda and t.dtype == torch.float32, (t.shape, t.stride())
+    return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
+
+
+class DenseFn(Function):
+    """tf.matmul(x, w) + bias (ops.py:163-165).  x may be a column slice of a wider matrix."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x, lda = _row_view(x)
+        w = _c(w)
+        M, K = x.shape
+        N = w.shape[1]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        gemm(x, w, y, M, N, K, lda, N, N, bias=bias)
+        ctx.x, ctx.w, ctx.bias, ctx.lda = x, w, bias, lda
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        x, w, bias, lda = ctx.x, ctx.w, ctx.bias, ctx.lda
+        M, K = x.shape
+        N = w.shape[1]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
+            gemm(dy, w, dx, M, K, N, N, N, K, transB=True)            # dx = dy @ w^T
+
+        def wg(out):
+            gemm(x, dy, out, K, N, M, lda, N, N, transA=True)         # dw = x^T @ dy
+        dw = param_grad(w, ctx.needs_input_grad[1], wg)
+        db = None
+        if bias is not None:
+            db = param_grad(bias, ctx.needs_input_grad[2], lambda out: _bias_grad(dy, out))
+        ctx.x = ctx.w = ctx.bias = None
+        return dx, dw, db
+
+
+class AttentionFn(Function):
+    """softmax(g f^T) h  (ops.py:481-485): q [B,N,dq], k [B,Nk,dq], v [B,Nk,dv] -> o [B,N,dv].
+    The [B,N,Nk] probabilities are materialised once (fp32) and kept for backward."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        q, k, v = _c(q), _c(k), _c(v)
+        B, N, dq = q.shape
+        Nk, dv = k.shape[1], v.shape[2]
+        L = lib()
+        p = torch.empty((B, N, Nk), dtype=torch.float32, device=q.device)
+        gemm(q, k, p, N, Nk, dq, dq, dq, Nk, transB=True, batch=B, sA=N * dq, sB=Nk * dq, sC=N * Nk)
+        check(L.bg_softmax_fwd(f32(p), f32(p), B * N, Nk, stream()))
+        o = torch.empty((B, N, dv), dtype=torch.float32, device=q.device)
+        gemm(p, v, o, N, dv, Nk, Nk, dv, dv, batch=B, sA=N * Nk, sB=Nk * dv, sC=N * dv)
+        ctx.save_for_backward(q, k, v, p)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        do = _c(do)
+        q, k, v, p = ctx.saved_tensors
+        B, N, dq = q.shape
+        Nk, dv = k.shape[1], v.shape[2]
+        L = lib()
+        dev = q.device
+        # dV = P^T dO
+        dvv = torch.empty_like(v)
+        gemm(p, do, dvv, Nk, dv, N, Nk, dv, dv, transA=True, batch=B, sA=N * Nk, sB=N * dv, sC=Nk * dv)
+        # dP = dO V^T ; dS = P * (dP - sum(dP*P))
+        dp = torch.empty((B, N, Nk), dtype=torch.float32, device=dev)
+        gemm(do, v, dp, N, Nk, dv, dv, dv, Nk, transB=True, batch=B, sA=N * dv, sB=Nk * dv, sC=N * Nk)
+        check(L.bg_softmax_bwd(f32(p), f32(dp), f32(dp), B * N, Nk, stream()))
+        # dQ = dS K ; dK = dS^T Q
+        dqq = torch.empty_like(q)
+        gemm(dp, k, dqq, N, dq, Nk, Nk, dq, dq, batch=B, sA=N * Nk, sB=Nk * dq, sC=N * dq)
+        dkk = torch.empty_like(k)
+        gemm(dp, q, dkk, Nk, dq, N, Nk, dq, dq, transA=True, batch=B, sA=N * Nk, sB=N * dq, sC=Nk * dq)
+        return dqq, dkk, dvv
+
+
+# ------------------------------------------------------------------------------------------
+# spectral norm
+# ------------------------------------------------------------------------------------------
+class SpectralNormFn(Function):
+    """One power iteration + w / sigma (ops.py:718-747).  ``u`` is updated in place (ops.py:743)."""
+
+    @staticmethod
+    def forward(ctx, w, u):
+        w = _c(w)
+        cols = w.shape[-1]
+        rows = w.numel() // cols
+        L = lib()
+        dev = w.device
+        wn = torch.empty_like(w)
+        v = torch.empty(rows, dtype=torch.float32, device=dev)
+        sigma = torch.empty(1, dtype=torch.float32, device=dev)
+        nb = L.bg_spectral_norm_workspace_bytes(rows, cols)
+        ws = workspace(nb, dev)
+        check(L.bg_spectral_norm_fwd(f32(w), f32(u), f32(u), f32(v), f32(sigma), f32(wn), rows, cols,
+                                     f32(ws), nb, stream()))
+        ctx.w, ctx.u, ctx.v, ctx.sigma, ctx.wn = w, u, v, sigma, wn
+        ctx.rows, ctx.cols = rows, cols
+        return wn
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        L = lib()
+        rows, cols = ctx.rows, ctx.cols
+        w, u, v, sigma, wn = ctx.w, ctx.u, ctx.v, ctx.sigma, ctx.wn
+
+        def prod(out):
+            ws = workspace(16, g.device)
+            check(L.bg_spectral_norm_bwd(f32(g), f32(wn), f32(u), f32(v), f32(sigma), f32(out), rows, cols,
+                                         f32(ws), 16, stream()))
+        dw = param_grad(w, ctx.needs_input_grad[0], prod)
+        ctx.w = ctx.wn = None
+        return dw, None
+
+
+# ------------------------------------------------------------------------------------------
+# batch norm (+ PReLU)
+# ------------------------------------------------------------------------------------------
+class BnActFn(Function):
+    """tf.nn.moments + tf.nn.batch_normalization (ops.py:630-638) / tf.layers.batch_normalization
+    (ops.py:581-585), optionally fused with the PReLU that follows (ops.py:532-537).
+
+    gamma/beta: [N,C] (per-sample, conditional BN) or [C].  ``reduce_fn`` (optional) all-reduces a
+    small fp32 tensor across data-parallel ranks in place (cross-replica statistics)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, alpha, moving_mean, moving_var, momentum, eps, unbiased_mv, is_training,
+                reduce_fn, world):
+        x = _c(x)
+        N, H, W_, C = x.shape
+        HW = H * W_
+        per_sample = int(gamma.dim() == 2)
+        L = lib()
+        dev = x.device
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        rstd = torch.empty(C, dtype=torch.float32, device=dev)
+        count = float(N * HW * world)
+        if is_training:
+            sums = torch.zeros(2 * C, dtype=torch.float32, device=dev)
+            check(L.bg_bn_stats(f32(x), f32(sums), N * HW, C, stream()))
+            if reduce_fn is not None:
+                reduce_fn(sums)
+            check(L.bg_bn_finalize(f32(sums), count, eps, momentum, int(unbiased_mv), f32(mean), f32(rstd),
+                                   f32(moving_mean), f32(moving_var), C, stream()))
+        else:
+            # inference: population statistics (ops.py:643)
+            sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+            sums[:C].copy_(moving_mean)
+            sums[C:].copy_(moving_var + moving_mean * moving_mean)
+            check(L.bg_bn_finalize(f32(sums), 1.0, eps, 0.0, 0, f32(mean), f32(rstd), None, None, C, stream()))
+        y = torch.empty_like(x)
+        gamma_c, beta_c = _c(gamma), _c(beta)
+        check(L.bg_bn_apply_act_fwd(f32(x), f32(mean), f32(rstd), f32(gamma_c), f32(beta_c), per_sample,
+                                    f32(alpha), f32(y), N, HW, C, stream()))
+        ctx.x, ctx.mean, ctx.rstd = x, mean, rstd
+        ctx.gamma, ctx.beta, ctx.alpha = gamma, beta, alpha
+        ctx.gamma_c, ctx.beta_c = gamma_c, beta_c
+        ctx.per_sample, ctx.count = per_sample, count
+        ctx.reduce_fn = reduce_fn
+        ctx.is_training = is_training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        x, mean, rstd = ctx.x, ctx.mean, ctx.rstd
+        gamma, beta, alpha = ctx.gamma, ctx.beta, ctx.alpha
+        N, H, W_, C = x.shape
+        HW = H * W_
+        L = lib()
+        dev = x.device
+        ps = ctx.per_sample
+        part = torch.empty((3, N, C), dtype=torch.float32, device=dev)
+        check(L.bg_bn_apply_act_bwd_reduce(f32(x), f32(dy), f32(mean), f32(rstd), f32(ctx.gamma_c), f32(ctx.beta_c),
+                                           ps, f32(alpha), f32(part), N, HW, C, stream()))
+        gshape = (N, C) if ps else (C,)
+        dgamma = torch.empty(gshape, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(gshape, dtype=torch.float32, device=dev)
+        dalpha = torch.empty(C, dtype=torch.float32, device=dev) if alpha is not None else None
+        cm = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        check(L.bg_bn_bwd_finalize(f32(part), f32(ctx.gamma_c), ps, ctx.count, f32(dgamma), f32(dbeta), f32(dalpha),
+                                   f32(cm), N, C, stream()))
+        if not ctx.is_training:
+            cm.zero_()                      # population statistics are constants
+        elif ctx.reduce_fn is not None:
+            ctx.reduce_fn(cm)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(L.bg_bn_apply_act_bwd_dx(f32(x), f32(dy), f32(mean), f32(rstd), f32(ctx.gamma_c), f32(ctx.beta_c),
+                                           ps, f32(alpha), f32(cm), f32(dx), N, HW, C, stream()))
+
+        def deliver(t, needed, g):
+            if not needed:
+                return None
+            if is_variable(t):
+                emit_grad(t, lambda out: out.copy_(g))
+                return None
+            return g
+        dg = deliver(gamma, ctx.needs_input_grad[1], dgamma)
+        db = deliver(beta, ctx.needs_input_grad[2], dbeta)
+        da = deliver(alpha, ctx.needs_input_grad[3], dalpha) if alpha is not None else None
+        ctx.x = None
+        return dx, dg, db, da, None, None, None, None, None, None, None, None
+
+
+class PReluFn(Function):
+    """ops.py:532-537 on [..., C]."""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = _c(x)
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        check(lib().bg_prelu_fwd(f32(x), f32(alpha), f32(y), x.numel() // C, C, stream()))
+        ctx.x, ctx.alpha = x, alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        x, alpha = ctx.x, ctx.alpha
+        C = x.shape[-1]
+        rows = x.numel() // C
+        L = lib()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(L.bg_prelu_bwd(f32(x), f32(dy), f32(alpha), f32(dx), None, rows, C, stream()))
+
+        def prod(out):
+            out.zero_()
+            check(L.bg_prelu_bwd(f32(x), f32(dy), f32(alpha), None, f32(out), rows, C, stream()))
+        da = param_grad(alpha, ctx.needs_input_grad[1], prod)
+        ctx.x = None
+        return dx, da
+
+
+# ------------------------------------------------------------------------------------------
+# pooling / small elementwise
+# ------------------------------------------------------------------------------------------
+class MaxPool2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, H, W_, C = x.shape
+        y = torch.empty((N, H // 2, W_ // 2, C), dtype=torch.float32, device=x.device)
+        check(lib().bg_maxpool2_fwd(f32(x), f32(y), N, H, W_, C, stream()))
+        ctx.x = x
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        x = ctx.x
+        N, H, W_, C = x.shape
+        dx = torch.empty_like(x)
+        check(lib().bg_maxpool2_bwd(f32(x), f32(dy), f32(dx), N, H, W_, C, stream()))
+        ctx.x = None
+        return dx
+
+
+class SumPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, H, W_, C = x.shape
+        y = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        check(lib().bg_sum_pool_fwd(f32(x), f32(y), N, H * W_, C, stream()))
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        N, H, W_, C = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        check(lib().bg_sum_pool_bwd(f32(dy), f32(dx), N, H * W_, C, stream()))
+        return dx
+
+
+class TanhFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(lib().bg_tanh_fwd(f32(x), f32(y), x.numel(), stream()))
+        ctx.y = y
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(lib().bg_tanh_bwd(f32(ctx.y), f32(dy), f32(dx), dy.numel(), stream()))
+        ctx.y = None
+        return dx
+
+
+class AddFn(Function):
+    """a + b (residual sums, ops.py:198,266,313)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        y = a.clone()
+        axpby(b, 1.0, y, 1.0)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class ScaleAddFn(Function):
+    """gamma * o + x with a learned scalar gamma (ops.py:486-490)."""
+
+    @staticmethod
+    def forward(ctx, o, gamma, x):
+        o, x = _c(o), _c(x)
+        y = torch.empty_like(x)
+        check(lib().bg_scale_add(f32(o), f32(gamma), f32(x), f32(y), x.numel(), stream()))
+        ctx.o, ctx.gamma = o, gamma
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        o, gamma = ctx.o, ctx.gamma
+        L = lib()
+        do = None
+        if ctx.needs_input_grad[0]:
+            do = torch.empty_like(o)
+            check(L.bg_scale_dev(f32(dy), f32(gamma), f32(do), dy.numel(), stream()))
+
+        def prod(out):
+            out.zero_()
+            check(L.bg_dot(f32(dy), f32(o), f32(out), dy.numel(), stream()))
+        dg = param_grad(gamma, ctx.needs_input_grad[1], prod)
+        ctx.o = None
+        return do, dg, dy
+
+
+# ------------------------------------------------------------------------------------------
+# DiffAugment
+# ------------------------------------------------------------------------------------------
+class DiffAugmentFn(Function):
+    """DiffAugment_tf.py:8-73 with explicit draws (device tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, u_b, u_s, u_c, t_x, t_y, o_x, o_y, policy_bits):
+        x = _c(x)
+        N, S, S2, C = x.shape
+        assert S == S2
+        y = torch.empty_like(x)
+        ws = torch.empty(N, dtype=torch.float32, device=x.device)
+        check(lib().bg_diffaugment_fwd(f32(x), f32(y), f32(u_b), f32(u_s), f32(u_c), i32(t_x), i32(t_y), i32(o_x),
+                                       i32(o_y), N, S, C, policy_bits, f32(ws), stream()))
+        ctx.draws = (u_s, u_c, t_x, t_y, o_x, o_y)
+        ctx.policy = policy_bits
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        u_s, u_c, t_x, t_y, o_x, o_y = ctx.draws
+        N, S, _, C = ctx.shape
+        dx = torch.empty_like(dy)
+        ws = torch.empty(N, dtype=torch.float32, device=dy.device)
+        check(lib().bg_diffaugment_bwd(f32(dy), f32(dx), f32(u_s), f32(u_c), i32(t_x), i32(t_y), i32(o_x), i32(o_y),
+                                       N, S, C, ctx.policy, f32(ws), stream()))
+        return dx, None, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------
+class HingeDLossFn(Function):
+    """discriminator_loss('hinge', real, fake, flood) (ops.py:788-797)."""
+
+    @staticmethod
+    def forward(ctx, real, fake, flood, reduce_fn, world):
+        real, fake = _c(real), _c(fake)
+        n = real.numel()
+        L = lib()
+        dev = real.device
+        sums = torch.zeros(2, dtype=torch.float32, device=dev)
+        check(L.bg_hinge_d_sums(f32(real), f32(fake), f32(sums), n, stream()))
+        if reduce_fn is not None:
+            reduce_fn(sums)
+        d_real = torch.empty_like(real)
+        d_fake = torch.empty_like(fake)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        check(L.bg_hinge_d_grad(f32(real), f32(fake), f32(sums), float(n * world), float(flood or 0.0), f32(d_real),
+                                f32(d_fake), f32(loss), n, stream()))
+        ctx.d_real, ctx.d_fake = d_real, d_fake
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        L = lib()
+        dr = torch.empty_like(ctx.d_real)
+        df = torch.empty_like(ctx.d_fake)
+        check(L.bg_scale_dev(f32(ctx.d_real), f32(g), f32(dr), dr.numel(), stream()))
+        check(L.bg_scale_dev(f32(ctx.d_fake), f32(g), f32(df), df.numel(), stream()))
+        return dr, df, None, None, None
+
+
+class HingeGLossFn(Function):
+    """generator_loss('hinge', fake, real, flood) (ops.py:832-840)."""
+
+    @staticmethod
+    def forward(ctx, fake, flood, reduce_fn, world):
+        fake = _c(fake)
+        n = fake.numel()
+        L = lib()
+        dev = fake.device
+        sums = torch.zeros(2, dtype=torch.float32, device=dev)
+        check(L.bg_hinge_g_sums(f32(fake), f32(sums), n, stream()))
+        if reduce_fn is not None:
+            reduce_fn(sums)
+        d_fake = torch.empty_like(fake)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        check(L.bg_hinge_g_grad(f32(sums), float(n * world), float(flood or 0.0), f32(d_fake), f32(loss), n,
+                                stream()))
+        ctx.d_fake = d_fake
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        df = torch.empty_like(ctx.d_fake)
+        check(lib().bg_scale_dev(f32(ctx.d_fake), f32(g), f32(df), df.numel(), stream()))
+        return df, None, None, None
+
+
+class OrthoCosineRegFn(Function):
+    """orthogonal_regularizer(scale, 'ortho_cosine')(w) (utils.py:180-235): scale * l2_loss(R).
+    The weight gradient dW = W (dA + dA^T) is produced in backward."""
+
+    @staticmethod
+    def forward(ctx, w, scale):
+        w = _c(w)
+        c = w.shape[-1]
+        rows = w.numel() // c
+        W2 = w.view(rows, c)
+        dev = w.device
+        A = torch.empty((c, c), dtype=torch.float32, device=dev)
+        gemm(W2, W2, A, c, c, rows, c, c, c, transA=True)               # A = W^T W
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        dA = torch.empty((c, c), dtype=torch.float32, device=dev)
+        check(lib().bg_ortho_cosine_fwd_bwd(f32(A), float(scale), f32(loss), f32(dA), c, stream()))
+        ctx.w, ctx.dA = w, dA
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        w, dA = ctx.w, ctx.dA
+        c = w.shape[-1]
+        rows = w.numel() // c
+        W2 = w.view(rows, c)
+
+        def prod(out):
+            o2 = out.view(rows, c)
+            gemm(W2, dA, o2, rows, c, c, c, c, c, alpha_dev=g)                                  # W dA
+            gemm(W2, dA, o2, rows, c, c, c, c, c, transB=True, alpha_dev=g, accumulate=True)    # + W dA^T
+        dw = param_grad(w, ctx.needs_input_grad[0], prod)
+        ctx.w = ctx.dA = None
+        return dw, None

@@ -1,0 +1,148 @@
+"""ctypes binding of ``libbiggan_hip.so`` (C ABI: ``include/biggan_hip.h``).
+
+The loader fails loudly: a missing library raises ImportError at first use, a non-zero return code
+raises RuntimeError with ``bg_last_error()``; tensors must be CUDA/fp32/contiguous.  Nothing here
+computes on the host.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_LIB = None
+LIB_NAME = "libbiggan_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+PAD_REFLECT, PAD_ZERO = 0, 1
+
+
+class BgConvDesc(Structure):
+    _fields_ = [(n, c_int32) for n in
+                ("N", "H", "W", "Cin", "Ho", "Wo", "Cout", "k", "stride", "pad_lo", "pad_mode")]
+
+
+class BgGemmDesc(Structure):
+    _fields_ = [("M", c_int32), ("N", c_int32), ("K", c_int32), ("transA", c_int32), ("transB", c_int32),
+                ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("batch", c_int32),
+                ("strideA", c_int64), ("strideB", c_int64), ("strideC", c_int64)]
+
+
+_P = c_void_p
+_CD = POINTER(BgConvDesc)
+_GD = POINTER(BgGemmDesc)
+
+# name -> (restype, argtypes); must list every symbol declared in include/biggan_hip.h
+SIGNATURES = {
+    "bg_abi_version": (c_int, []),
+    "bg_last_error": (c_char_p, []),
+    "bg_target_arch": (c_char_p, []),
+    "bg_conv2d_fwd": (c_int, [_CD, _P, _P, _P, _P, _P, c_int, _P]),
+    "bg_conv2d_dgrad": (c_int, [_CD, _P, _P, _P, _P, c_int, _P]),
+    "bg_conv2d_wgrad_workspace_bytes": (c_size_t, [_CD]),
+    "bg_conv2d_wgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
+    "bg_deconv2d_fwd": (c_int, [_CD, _P, _P, _P, _P, _P, c_int, _P]),
+    "bg_deconv2d_dgrad": (c_int, [_CD, _P, _P, _P, _P, c_int, _P]),
+    "bg_deconv2d_wgrad_workspace_bytes": (c_size_t, [_CD]),
+    "bg_deconv2d_wgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
+    "bg_gemm_workspace_bytes": (c_size_t, [_GD]),
+    "bg_gemm": (c_int, [_GD, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "bg_spectral_norm_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "bg_spectral_norm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
+    "bg_spectral_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
+    "bg_bn_stats": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "bg_bn_finalize": (c_int, [_P, c_double, c_float, c_float, c_int, _P, _P, _P, _P, c_int, _P]),
+    "bg_bn_apply_act_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
+    "bg_bn_apply_act_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
+    "bg_bn_apply_act_bwd_dx": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "bg_bn_bwd_finalize": (c_int, [_P, _P, c_int, c_double, _P, _P, _P, _P, c_int, c_int, _P]),
+    "bg_prelu_fwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
+    "bg_prelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P]),
+    "bg_maxpool2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "bg_maxpool2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "bg_softmax_fwd": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "bg_softmax_bwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
+    "bg_sum_pool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "bg_sum_pool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "bg_axpby": (c_int, [_P, c_float, _P, c_float, c_int64, _P]),
+    "bg_scale_add": (c_int, [_P, _P, _P, _P, c_int64, _P]),
+    "bg_dot": (c_int, [_P, _P, _P, c_int64, _P]),
+    "bg_scale_dev": (c_int, [_P, _P, _P, c_int64, _P]),
+    "bg_tanh_fwd": (c_int, [_P, _P, c_int64, _P]),
+    "bg_tanh_bwd": (c_int, [_P, _P, _P, c_int64, _P]),
+    "bg_bias_grad": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "bg_diffaugment_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "bg_diffaugment_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "bg_hinge_d_sums": (c_int, [_P, _P, _P, c_int, _P]),
+    "bg_hinge_d_grad": (c_int, [_P, _P, _P, c_double, c_float, _P, _P, _P, c_int, _P]),
+    "bg_hinge_g_sums": (c_int, [_P, _P, c_int, _P]),
+    "bg_hinge_g_grad": (c_int, [_P, c_double, c_float, _P, _P, c_int, _P]),
+    "bg_ortho_cosine_fwd_bwd": (c_int, [_P, c_float, _P, _P, c_int, _P]),
+    "bg_adam_tf_ema_step": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_float,
+                                    c_int64, _P]),
+    "bg_prof_enable": (None, [c_int]),
+    "bg_prof_reset": (None, []),
+    "bg_prof_collect": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+}
+
+
+def lib():
+    """The loaded library (loads on first call).  Raises ImportError if it was not built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % (LIB_NAME, LIB_PATH))
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if L.bg_abi_version() != 1:
+            raise ImportError("libbiggan_hip.so ABI version %d != 1" % L.bg_abi_version())
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libbiggan_hip: " + lib().bg_last_error().decode())
+
+
+def ptr(t):
+    """Device pointer of a CUDA fp32 / int32 contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("biggan_tensorflow_amd ops run on the MI355X only: got a %s tensor "
+                           "(there is no CPU fallback)" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("tensor must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+def f32(t):
+    if t is not None and t.dtype != torch.float32:
+        raise RuntimeError("expected float32, got %s" % t.dtype)
+    return ptr(t)
+
+
+def i32(t):
+    if t is not None and t.dtype != torch.int32:
+        raise RuntimeError("expected int32, got %s" % t.dtype)
+    return ptr(t)
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def conv_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode):
+    return BgConvDesc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode)
+
+
+def workspace(nbytes, device):
+    """Scratch from PyTorch's caching allocator (no allocation inside the library)."""
+    n = max(int(nbytes), 16)
+    return torch.empty((n + 3) // 4, dtype=torch.float32, device=device)

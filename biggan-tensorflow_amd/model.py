@@ -1,0 +1,469 @@
+"""``BigGAN`` with the reference's ``generator`` / ``discriminator`` topology and train ops
+(``/root/reference/BigGAN.py:246-715, 768-961``; option plumbing ``GANBase.py:13-55``) executing
+eagerly on one MI355X per process.  One training iteration = D step then G step
+(BigGAN.py:1061-1084); each step is one "run" with its own z, DiffAugment draws and one spectral-norm
+power iteration per weight.
+
+Out-of-scope reference features (deep blocks, alternative heads, reconstruction
+heads, class conditioning, non-hinge losses, gradient penalty, renorm) are accepted as flags and
+rejected here with NotImplementedError.
+"""
+import copy
+import math
+import time
+
+import torch
+
+from . import ops
+from . import scope as S
+from . import hip
+from .ops import (fully_connected, resblock_up_condition, resblock_down, resblock, self_attention_2, conv, bn,
+                  prelu, relu, lrelu, tanh, global_sum_pooling, discriminator_loss, generator_loss)
+from .DiffAugment import DiffAugment, draw as draw_augment
+from .utils import orthogonal_regularizer, orthogonal_regularizer_fc, round_up
+
+
+class GANBase(object):
+    """GANBase.py:13-55 (attribute plumbing, bn/conv option dicts, da_policy expansion)."""
+
+    def __init__(self, args):
+        self.dataset_name = args.dataset
+        self.checkpoint_dir = args.checkpoint_dir
+        self.sample_dir = args.sample_dir
+        self.result_dir = args.result_dir
+        self.log_dir = args.log_dir
+        self.epoch = args.epoch
+        self.iterations_per_epoch = args.iteration
+        self.batch_size = args.batch_size
+        self.virtual_batches = args.virtual_batches
+        self.print_freq = args.print_freq
+        self.save_freq = args.save_freq
+        self.img_size = args.img_size
+        self.bn_options = {"type": args.bn_type, "momentum": args.bn_momentum}       # GANBase.py:39-47
+        if self.bn_options["type"] == 'batch_renorm':
+            raise NotImplementedError("--bn_type batch_renorm is outside the default hot path")
+        self.conv_options = {"padding_type": args.conv_padding, "sn": args.sn}       # GANBase.py:49-51
+        self.da_policy = args.da_policy
+        if self.da_policy == 'full':
+            self.da_policy = 'color,translation,cutout'                               # GANBase.py:53-55
+
+
+class BigGAN(GANBase):
+    def __init__(self, args, device="cuda", store=None, process_group=None, seed=42):
+        GANBase.__init__(self, args)
+        self.model_name = "BigGAN"
+        self.args = args
+        self.device = torch.device(device)
+        self.depth = args.img_size.bit_length() - 2                                   # BigGAN.py:19
+
+        unsupported = [
+            ("deep", args.deep), ("n_labels>0", args.n_labels > 0), ("cls_embedding", args.cls_embedding),
+            ("shared_z", args.shared_z > 0), ("g_z_dense_concat", args.g_z_dense_concat),
+            ("g_other_level_dense_layer", args.g_other_level_dense_layer),
+            ("g_no_last_resblock", args.g_no_last_resblock), ("g_mixed_resblocks", args.g_mixed_resblocks),
+            ("g_final_layer", args.g_final_layer), ("multi_head", args.multi_head),
+            ("z_reconstruct", args.z_reconstruct), ("d_reconstruction", args.d_reconstruction),
+            ("d_reconstruction_halfres", args.d_reconstruction_halfres),
+            ("d_reconstruction_texture", args.d_reconstruction_texture), ("d_final_conv", args.d_final_conv),
+            ("bn_in_d", args.bn_in_d), ("c_dim!=3", args.c_dim != 3), ("virtual_batches>1", args.virtual_batches > 1),
+            ("not g_first_level_dense_layer", not args.g_first_level_dense_layer),
+        ]
+        bad = [n for n, v in unsupported if v]
+        if bad:
+            raise NotImplementedError("flags outside the MI355X hot path (SURVEY.md section 8): " + ", ".join(bad))
+        self.gan_type = args.gan_type
+        self.d_loss_func = args.d_loss_func if args.d_loss_func else self.gan_type     # BigGAN.py:127-128
+        if self.gan_type != 'hinge' or self.d_loss_func != 'hinge':
+            raise NotImplementedError("only --gan_type hinge is on the hot path (got %s / %s)"
+                                      % (self.gan_type, self.d_loss_func))
+
+        self.activation = args.activation                                              # BigGAN.py:71-83
+        if self.activation == 'relu':
+            self.activation_fn = relu
+        elif self.activation == 'prelu':
+            self.activation_fn = prelu
+        elif self.activation == 'lrelu':
+            raise NotImplementedError("--activation lrelu is outside the default hot path")
+        else:
+            raise ValueError("Unknown activation function: " + str(self.activation))
+
+        self.ch = args.ch
+        self.d_ch = args.d_ch if args.d_ch > 0 else args.ch                            # BigGAN.py:153-154
+        self.upsampling_method = args.upsampling_method
+        self.downsampling_method = args.downsampling_method
+        self.g_conv = args.g_conv
+        self.g_grow_factor = args.g_grow_factor
+        self.d_grow_factor = args.d_grow_factor
+        self.g_regularization_method = args.g_regularization
+        self.g_regularization_factor = args.g_regularization_factor
+        self.g_sa_size = args.g_sa_size if args.g_sa_size != 0 else args.sa_size       # BigGAN.py:110-117
+        self.d_sa_size = args.d_sa_size if args.d_sa_size != 0 else args.sa_size
+        self.z_dim = args.z_dim
+        self.first_split_ratio = args.first_split_ratio
+        if self.z_dim % self.depth != 0 and self.first_split_ratio == 1:               # BigGAN.py:122-124
+            self.z_dim = self.z_dim + self.depth - self.z_dim % self.depth
+        self.g_flood, self.d_flood = args.g_flood, args.d_flood
+        self.n_critic = args.n_critic
+        self.sn = args.sn
+        self.d_use_bias = args.bias_in_d
+        self.bias_in_sa = args.bias_in_sa
+        self.bn_in_d = args.bn_in_d
+        self.c_dim = args.c_dim
+        self.g_rgb_mix_kernel = args.g_rgb_mix_kernel
+        self.z_trunc_train = args.z_trunc_train
+        self.g_learning_rate, self.d_learning_rate = args.g_lr, args.d_lr
+        self.beta1, self.beta2 = args.beta1, args.beta2
+        self.moving_decay = args.moving_decay
+        self.d_compat_use_sn_in_critic_output = args.d_compat_use_sn_in_critic_output
+        self.extension_32 = getattr(args, "extension_32", False)
+
+        self.store = store if store is not None else S.VariableStore(self.device, seed)
+        S.set_default_store(self.store)
+        self.pg = process_group
+        self.world = 1
+        self.rank = 0
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+            self.rank = torch.distributed.get_rank(process_group)
+        self.gen = torch.Generator(device=self.device) if self.device.type == "cuda" else None
+        if self.gen is not None:
+            self.gen.manual_seed(1234 + self.rank)
+        self.built = False
+
+    ##################################################################################
+    # Generator  (BigGAN.py:236-582)
+    ##################################################################################
+    def round_up(self, val, multiple):
+        return (int(val) + multiple - 1) // multiple * multiple
+
+    def scale_channels(self, ch, factor):
+        return self.round_up(int(ch * factor), 8)
+
+    def g_channels_for_block(self, b_i, b_count):
+        return self.scale_channels(self.ch, self.g_grow_factor ** (b_count - b_i - 1))
+
+    def g_block_info(self):                                                            # BigGAN.py:290-294
+        s = self.img_size
+        if s == 64: info = {"counts": [1, 1, 1, 1], "sa_index": 3}
+        elif s == 128: info = {"counts": [1, 1, 1, 1, 1], "sa_index": 4}
+        elif s == 256: info = {"counts": [1, 2, 1, 1, 1], "sa_index": 3}
+        elif s == 512: info = {"counts": [1, 2, 1, 1, 2], "sa_index": 3}
+        elif s == 32 and self.extension_32: info = {"counts": [1, 1, 1], "sa_index": 2}
+        else: raise ValueError("Invalid image size specified: " + str(self.img_size))
+        if self.g_sa_size != 0:
+            self.set_sa_index(info, self.g_sa_size)
+        return info
+
+    def d_block_info(self):                                                            # BigGAN.py:607-611
+        s = self.img_size
+        if s == 64: info = {"counts": [1, 1, 1, 1], "sa_index": 1}
+        elif s == 128: info = {"counts": [1, 1, 1, 1, 1], "sa_index": 1}
+        elif s == 256: info = {"counts": [1, 1, 1, 2, 1], "sa_index": 2}
+        elif s == 512: info = {"counts": [1, 2, 1, 1, 2], "sa_index": 2}
+        elif s == 32 and self.extension_32: info = {"counts": [1, 1, 1], "sa_index": 1}
+        else: raise ValueError("Invalid image size specified: " + str(self.img_size))
+        if self.d_sa_size != 0:
+            self.set_sa_index(info, self.d_sa_size, scaling_down=True)
+        return info
+
+    def set_sa_index(self, block_info, sa_size, scaling_down=False):
+        """BigGAN.py:1457-1480."""
+        if sa_size < 0:
+            block_info["sa_index"] = -1
+            return
+        cur_f_size = self.img_size if scaling_down else 4
+        for i, bs in enumerate(block_info["counts"]):
+            for j in range(bs):
+                if scaling_down:
+                    cur_f_size //= 2
+                else:
+                    cur_f_size *= 2
+            if scaling_down:
+                met_goal = cur_f_size <= sa_size
+            else:
+                met_goal = cur_f_size >= sa_size
+            if met_goal or i == len(block_info["counts"]) - 1:
+                block_info["sa_index"] = i + 1
+                break
+        if cur_f_size != sa_size:
+            print("Warning: moving self-attention to " + str(cur_f_size) + "x" + str(cur_f_size) + " feature maps")
+
+    def z_split_sizes(self):                                                           # BigGAN.py:280-288
+        if self.first_split_ratio > 1:
+            split_dim = self.z_dim // (self.depth - 1 + self.first_split_ratio)
+            first_split_dim = self.z_dim - (self.depth - 1) * split_dim
+        else:
+            split_dim = self.z_dim // self.depth
+            first_split_dim = split_dim
+        return [first_split_dim] + ([split_dim] * (self.depth - 1))
+
+    def generator(self, z, cls_z=None, is_training=True, reuse=False, custom_getter=None, simple_head=False):
+        opt = {"sn": self.sn, "is_training": is_training, "upsampling_method": self.upsampling_method,
+               "g_conv": self.g_conv, "act": self.activation_fn, "self_attention_bias": self.bias_in_sa,
+               "bn": copy.deepcopy(self.bn_options), "conv": copy.deepcopy(self.conv_options)}
+        if is_training:                                                                # BigGAN.py:257-274
+            m = self.g_regularization_method
+            if m == 'none':
+                opt["conv"]["regularizer"] = None
+                opt["fc_regularizer"] = None
+            elif m in ('ortho', 'ortho_cosine'):
+                opt["conv"]["regularizer"] = orthogonal_regularizer(self.g_regularization_factor, type=m)
+                opt["fc_regularizer"] = orthogonal_regularizer_fc(self.g_regularization_factor, type=m)
+            elif m == 'l2':
+                raise NotImplementedError("--g_regularization l2 is outside the default hot path")
+            else:
+                raise ValueError("Unknown regularization method: " + str(m))
+        else:
+            opt["conv"]["regularizer"] = None
+            opt["fc_regularizer"] = None
+
+        with S.variable_scope("generator", reuse=reuse):
+            block_info = self.g_block_info()
+            split_sizes = self.z_split_sizes()
+            z2 = z.reshape(z.shape[0], -1)
+            z_split = list(torch.split(z2, split_sizes, dim=-1))                       # BigGAN.py:335 (views)
+            next_zi = [0]
+
+            def next_z_split():
+                zi = next_zi[0]
+                next_zi[0] += 1
+                return z_split[zi], split_sizes[zi]
+
+            counts = block_info["counts"]
+            ch_mul = 2 ** (len(counts) - 1)                                            # BigGAN.py:427
+            ch = self.g_channels_for_block(0, len(counts))
+
+            layer_z, z_dim = next_z_split()
+            f_width = self.round_up((z_dim + 0) * 1.85, 8)                             # BigGAN.py:433
+            if self.activation_fn is relu:                                             # BigGAN.py:434-438
+                x = fully_connected(layer_z, units=f_width, scope='dense1', opt=opt)
+                x = relu(x)
+                x = fully_connected(x, units=4 * 4 * ch, scope='dense2', opt=opt)
+            else:
+                with S.variable_scope('first'):                                        # BigGAN.py:440-443
+                    x = fully_connected(layer_z, units=f_width, scope='dense1', opt=opt)
+                    x = opt["act"](x)
+                    x = fully_connected(x, units=4 * 4 * ch, scope='dense2', opt=opt)
+            x = x.reshape(-1, 4, 4, ch)                                                # BigGAN.py:446
+
+            b_i = 0
+            for block_count in counts:                                                 # BigGAN.py:449-489
+                scope = 'resblock_up_' + str(ch_mul)
+                for sb_i in range(block_count):
+                    layer_z, z_dim = next_z_split()
+                    if block_count > 1:
+                        scope = scope + '_' + str(sb_i)                                # cumulative (BigGAN.py:455)
+                    x = resblock_up_condition(x, layer_z, channels=ch, use_bias=False, opt=opt, scope=scope)
+                b_i += 1
+                if b_i == block_info["sa_index"]:
+                    x = self_attention_2(x, channels=ch, opt=opt, scope='self_attention')
+                ch = self.g_channels_for_block(b_i, len(counts))
+                ch_mul = ch_mul // 2
+
+            x = ops._bn_act(x, None, opt)                                              # BigGAN.py:491-492
+            x = conv(x, channels=self.c_dim, kernel=self.g_rgb_mix_kernel, stride=1, pad=1, use_bias=False, opt=opt,
+                     scope='G_logit')                                                  # BigGAN.py:570
+            x = tanh(x)                                                                # BigGAN.py:580
+            return x
+
+    ##################################################################################
+    # Discriminator  (BigGAN.py:588-715)
+    ##################################################################################
+    def d_channels_for_block(self, b_i):
+        return self.scale_channels(self.d_ch, self.d_grow_factor ** b_i)
+
+    def make_opt_with_sn(self, src_opt, sn):
+        """BigGAN.py:1482-1487."""
+        sn_opt = copy.copy(src_opt)
+        sn_opt["conv"] = copy.copy(src_opt["conv"])
+        sn_opt["sn"] = sn
+        sn_opt["conv"]["sn"] = sn
+        return sn_opt
+
+    def discriminator(self, x, is_training=True, reuse=False):
+        opt = {"sn": self.sn, "is_training": is_training, "bn_in_d": self.bn_in_d, "act": self.activation_fn,
+               "downsampling_method": self.downsampling_method, "self_attention_bias": self.bias_in_sa,
+               "bn": copy.deepcopy(self.bn_options), "conv": copy.deepcopy(self.conv_options)}
+        outputs = {}
+        with S.variable_scope("discriminator", reuse=reuse):
+            ch = self.d_channels_for_block(0)
+            block_info = self.d_block_info()
+            b_i = 0
+            ch_mul = 1
+            for block_count in block_info["counts"]:                                   # BigGAN.py:624-664
+                scope = 'resblock_down_' + str(ch_mul)
+                for sb_i in range(block_count):
+                    if block_count > 1:
+                        scope = scope + '_' + str(sb_i)
+                    x = resblock_down(x, channels=ch, use_bias=self.d_use_bias, opt=opt, scope=scope)
+                b_i += 1
+                if b_i == block_info["sa_index"]:
+                    x = self_attention_2(x, channels=ch, opt=opt, scope='self_attention')
+                ch = self.d_channels_for_block(b_i)
+                ch_mul = ch_mul * 2
+            ch = self.d_channels_for_block(b_i - 1)                                    # BigGAN.py:666
+            x = resblock(x, channels=ch, use_bias=self.d_use_bias, opt=opt, scope='resblock')
+            x = opt["act"](x)
+            features = global_sum_pooling(x)                                           # BigGAN.py:671
+            critic_opt = self.make_opt_with_sn(opt, self.d_compat_use_sn_in_critic_output)
+            x = fully_connected(features, units=1, opt=critic_opt, scope='D_logit')    # BigGAN.py:681-682
+            outputs["real"] = x
+            return outputs
+
+    ##################################################################################
+    # Model  (BigGAN.py:768-961)
+    ##################################################################################
+    def build_model(self):
+        """Create every variable (one shape-only pass), pack trainables into flat arenas, set up the
+        optimiser state (BigGAN.py:913-930: Adam for D; MovingAverageOptimizer(Adam) for G)."""
+        B = 2
+        z = torch.empty(B, 1, 1, self.z_dim, device="meta")
+        img = self.generator(z, None, is_training=True)
+        assert tuple(img.shape) == (B, self.img_size, self.img_size, self.c_dim), img.shape
+        out = self.discriminator(img)
+        assert tuple(out["real"].shape) == (B, 1)
+        self.store.pack()
+        self.g_arena = self.store.arenas["generator"]
+        self.d_arena = self.store.arenas["discriminator"]
+        self.d_vars = self.store.trainable_variables('discriminator')                  # BigGAN.py:915-917
+        self.g_vars = self.store.trainable_variables('generator')
+        self.counter = 0
+        self.built = True
+        return self
+
+    # ---- data-parallel hooks -----------------------------------------------------------------
+    def _reduce_fn(self):
+        if self.world == 1:
+            return None
+        pg = self.pg
+
+        def red(t):
+            torch.distributed.all_reduce(t, group=pg)
+        return red
+
+    def _allreduce_grads(self, arena):
+        if self.world > 1:
+            from .parallel import allreduce_flat
+            allreduce_flat(arena.grads, self.pg)
+
+    def _adam(self, arena, lr, with_ema):
+        arena.step += 1
+        t = arena.step
+        lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)        # tf.train.AdamOptimizer
+        hip.check(hip.lib().bg_adam_tf_ema_step(
+            hip.f32(arena.params), hip.f32(arena.grads), hip.f32(arena.m), hip.f32(arena.v),
+            hip.f32(arena.ema) if with_ema else None, lr_t, self.beta1, self.beta2, 1e-8, self.moving_decay, 1.0,
+            arena.size, hip.stream()))
+
+    def sample_z(self, B):
+        z = torch.empty(B, 1, 1, self.z_dim, dtype=torch.float32, device=self.device)
+        if self.z_trunc_train:                                                         # BigGAN.py:790-793
+            torch.nn.init.trunc_normal_(z, 0.0, 1.0, -2.0, 2.0, generator=self.gen)
+        else:
+            z.normal_(generator=self.gen)
+        return z
+
+    def _set_requires_grad(self, variables, flag):
+        for v in variables.values():
+            v.requires_grad_(flag)
+
+    # ---- the two train ops -------------------------------------------------------------------------
+    def d_forward(self, real, z=None, draws_real=None, draws_fake=None):
+        """BigGAN.py:806-808, 856-883: D(aug(real)), D(aug(G(z))), hinge + flood.  G runs without a
+        backward graph (d_loss is minimised over d_vars only); real and fake go through D as one batch."""
+        B = real.shape[0]
+        ops.begin_run(self._reduce_fn(), self.world)
+        if z is None:
+            z = self.sample_z(B)
+        with torch.no_grad():
+            fake = self.generator(z, None, is_training=True)
+        real_aug = DiffAugment(real, policy=self.da_policy, draws=draws_real, generator=self.gen)
+        fake_aug = DiffAugment(fake, policy=self.da_policy, draws=draws_fake, generator=self.gen)
+        logits = self.discriminator(torch.cat([real_aug, fake_aug], dim=0))["real"]
+        real_logits, fake_logits = logits[:B], logits[B:]
+        d_loss = discriminator_loss(self.d_loss_func, real=real_logits, fake=fake_logits, flood_level=self.d_flood)
+        return {"d_loss": d_loss, "real_logits": real_logits, "fake_logits": fake_logits, "fake": fake}
+
+    def d_step(self, real, z=None, draws_real=None, draws_fake=None, apply=True):
+        out = self.d_forward(real, z, draws_real, draws_fake)
+        self.store.begin_backward("discriminator")
+        out["d_loss"].backward()
+        self.store.zero_untouched("discriminator")
+        self._allreduce_grads(self.d_arena)
+        if apply:
+            self._adam(self.d_arena, self.d_learning_rate, with_ema=False)
+        return out
+
+    def g_forward(self, B, z=None, draws_fake=None):
+        """BigGAN.py:896-898: -mean(D(aug(G(z)))) + flood + regularisation losses."""
+        ops.begin_run(self._reduce_fn(), self.world)
+        if z is None:
+            z = self.sample_z(B)
+        fake = self.generator(z, None, is_training=True)
+        fake_aug = DiffAugment(fake, policy=self.da_policy, draws=draws_fake, generator=self.gen)
+        fake_logits = self.discriminator(fake_aug)["real"]
+        g_adv = generator_loss(self.gan_type, fake=fake_logits, real=None, flood_level=self.g_flood)
+        regs = ops.get_regularization_losses() if self.g_regularization_method != 'none' else []
+        return {"g_adv": g_adv, "regs": regs, "fake_logits": fake_logits, "fake": fake}
+
+    def g_step(self, B, z=None, draws_fake=None, apply=True):
+        self._set_requires_grad(self.d_vars, False)        # g_loss is minimised over g_vars only
+        try:
+            out = self.g_forward(B, z, draws_fake)
+            self.store.begin_backward("generator")
+            roots = [out["g_adv"]] + out["regs"]
+            ones = torch.ones(1, dtype=torch.float32, device=self.device)
+            # regularisation terms are replicated on every rank: weight them 1/world so that the
+            # SUM all-reduce of the flat gradient arena yields the single-process gradient
+            rw = ones if self.world == 1 else ones / self.world
+            torch.autograd.backward(roots, [ones] + [rw] * len(out["regs"]))
+        finally:
+            self._set_requires_grad(self.d_vars, True)
+        self.store.zero_untouched("generator")
+        self._allreduce_grads(self.g_arena)
+        if apply:
+            self._adam(self.g_arena, self.g_learning_rate, with_ema=True)
+        if out["regs"]:
+            out["g_reg"] = torch.stack([r.detach() for r in out["regs"]]).sum()
+            out["g_loss"] = out["g_adv"].detach() + out["g_reg"]
+        else:
+            out["g_reg"] = torch.zeros(1, device=self.device)
+            out["g_loss"] = out["g_adv"].detach()
+        return out
+
+    def train_step(self, real):
+        """One iteration of BigGAN.py:1061-1084."""
+        losses = {}
+        d = self.d_step(real)
+        losses["d_loss"] = d["d_loss"]
+        if (self.counter - 1) % self.n_critic == 0:                                    # BigGAN.py:1080
+            g = self.g_step(real.shape[0])
+            losses["g_loss"] = g["g_loss"]
+        self.counter += 1
+        return losses
+
+    def synthetic_batch(self, B=None):
+        """Synthetic images U(-1,1) [B,S,S,c_dim] on the device (the reference reads PNG files)."""
+        B = B or self.batch_size
+        return torch.rand(B, self.img_size, self.img_size, self.c_dim, device=self.device,
+                          generator=self.gen) * 2.0 - 1.0
+
+    def train(self, data_fn=None, iterations=None):
+        """BigGAN.py:1015-1118 training loop (synthetic data unless ``data_fn`` is given)."""
+        start_time = time.time()
+        n = iterations if iterations is not None else self.epoch * self.iterations_per_epoch
+        for _ in range(n):
+            real = data_fn() if data_fn is not None else self.synthetic_batch()
+            losses = self.train_step(real)
+            vals = {k: float(v.item()) for k, v in losses.items()}
+            print_str = "Step: %5d, time: %4.4f" % (self.counter, time.time() - start_time)   # BigGAN.py:1109-1116
+            for name, val in vals.items():
+                print_str += ", " + name + ": %.4f" % val
+            print(print_str, flush=True)
+
+    @property
+    def model_dir(self):
+        """BigGAN.py:1246-1253."""
+        sn = '_sn' if self.sn else ''
+        return "{}_{}_{}_{}_{}{}".format(self.model_name, self.dataset_name, self.gan_type, self.img_size,
+                                         self.z_dim, sn)

@@ -1,0 +1,573 @@
+"""Operator library with the reference's ``ops.py`` function names, signatures, ``opt`` keys and
+scope naming (``/root/reference/ops.py``), executing eagerly on MI355X through libbiggan_hip.so.
+
+Tensors are NHWC fp32 CUDA tensors; parameters are created / reused implicitly by scope path
+(``scope.py``).  A tensor on the ``meta`` device only propagates shapes and registers variables
+(used to build the parameter manifest without a GPU); any other non-CUDA tensor raises.
+"""
+import torch
+
+from . import functional as Fn
+from . import hip
+from . import scope as S
+from .scope import variable_scope, get_variable
+from .utils import round_up  # noqa: F401  (ops.py:16)
+
+##################################################################################
+# Initialization (ops.py:13-14)
+##################################################################################
+weight_init = S.truncated_normal_initializer(mean=0.0, stddev=0.02)
+gan_dtype = torch.float32
+
+
+##################################################################################
+# per-run context: spectral-norm cache, regularisation losses, data-parallel hooks
+##################################################################################
+class _Run:
+    def __init__(self):
+        self.sn_cache = {}       # variable name -> w / sigma of this run (one power iteration per run)
+        self.reg_losses = []     # tf.losses.get_regularization_losses()
+        self.reg_seen = set()
+        self.reduce_fn = None    # in-place SUM all-reduce of a small fp32 tensor across DP ranks
+        self.world = 1
+
+
+_run = _Run()
+
+
+def begin_run(reduce_fn=None, world=1):
+    """Start of one ``sess.run``: forget cached spectral norms and regularisation losses."""
+    _run.sn_cache = {}
+    _run.reg_losses = []
+    _run.reg_seen = set()
+    _run.reduce_fn = reduce_fn
+    _run.world = world
+
+
+def get_regularization_losses():
+    return list(_run.reg_losses)
+
+
+def _is_meta(x):
+    return x.device.type == "meta"
+
+
+def _meta(shape):
+    return torch.empty(tuple(int(s) for s in shape), device="meta")
+
+
+def _regularize(w, regularizer):
+    """tf.get_variable(..., regularizer=...) adds regularizer(w) to the graph's losses once per variable."""
+    if regularizer is None or not torch.is_grad_enabled() or not w.requires_grad:
+        return
+    if w.bg_name in _run.reg_seen:
+        return
+    _run.reg_seen.add(w.bg_name)
+    if _is_meta(w) or not w.is_cuda:
+        return
+    _run.reg_losses.append(regularizer(w))
+
+
+##################################################################################
+# Layer
+##################################################################################
+def subpixel_conv(x, channels, opt, kernel=3, scale=2, use_bias=True, scope='subpixel_conv_0'):
+    raise NotImplementedError("subpixel_conv (ops.py:23) is outside the default hot path")
+
+
+def decode_kernel_sizes(str):
+    raise NotImplementedError("mixed-kernel convolutions (ops.py:29) are outside the default hot path")
+
+
+def encode_kernel_sizes(slices, ch_mul=1.0):
+    raise NotImplementedError("mixed-kernel convolutions (ops.py:44) are outside the default hot path")
+
+
+def conv(x, channels, opt, kernel=4, stride=2, pad=0, dilation=1, use_bias=True, scope='conv_0'):
+    """ops.py:49-113."""
+    with variable_scope(scope) as full_scope:
+        if isinstance(kernel, str):
+            raise NotImplementedError("mixed-kernel convolutions (ops.py:52-59) are outside the default hot path")
+        if dilation != 1:
+            raise NotImplementedError("dilation != 1")
+        N, H, W, Cin = x.shape
+        pad_mode = hip.PAD_REFLECT
+        pad_lo = pad_hi = 0
+        if pad > 0:
+            pad_type = opt.get("conv", {}).get("padding_type", 'reflect')
+            if H % stride == 0:                       # ops.py:68-71
+                tot = pad * 2
+            else:
+                tot = max(kernel - (H % stride), 0)
+            pad_lo = int(tot // 2)
+            pad_hi = int(tot - pad_lo)
+            if pad_type == 'zero':                    # TF 'SAME'
+                pad_mode = hip.PAD_ZERO
+                out = -(-H // stride)
+                tot = max((out - 1) * stride + kernel - H, 0)
+                pad_lo, pad_hi = tot // 2, tot - tot // 2
+            elif pad_type == 'reflect':
+                pad_mode = hip.PAD_REFLECT
+            else:
+                raise ValueError("Unsupported padding type: " + str(pad_type))
+        Ho = (H + pad_lo + pad_hi - kernel) // stride + 1
+        Wo = (W + pad_lo + pad_hi - kernel) // stride + 1
+
+        sn = opt.get("conv", {}).get("sn", True)
+        reg = opt.get("conv", {}).get("regularizer", None) if 'generator' in full_scope else None
+        w = get_variable("kernel", shape=[kernel, kernel, Cin, channels], initializer=weight_init, regularizer=reg)
+        _regularize(w, reg)
+        bias = None
+        if sn:
+            wk = spectral_norm(w, _shape_only=_is_meta(x))
+            if use_bias:
+                bias = get_variable("bias", [channels], initializer=S.constant_initializer(0.0))
+        else:
+            wk = w
+            if use_bias:
+                bias = get_variable("bias", [channels], initializer=S.constant_initializer(0.0))
+        if _is_meta(x):
+            return _meta((N, Ho, Wo, channels))
+        return Fn.Conv2dFn.apply(x, wk, bias, stride, pad_lo, Ho, Wo, pad_mode)
+
+
+def deconv(x, channels, opt, kernel=4, stride=2, padding='SAME', use_bias=True, scope='deconv_0', _accumulate_into=None):
+    """ops.py:116-139.  ``_accumulate_into`` (extension): add the result into an existing tensor
+    in the kernel epilogue (fused residual sum)."""
+    with variable_scope(scope):
+        N, H, W, Cin = x.shape
+        if padding != 'SAME':
+            raise NotImplementedError("deconv padding != 'SAME'")
+        tot = max((H - 1) * stride + kernel - stride * H, 0)        # TF SAME transposed alignment
+        pad_lo = tot // 2
+        reg = opt.get("conv", {}).get("regularizer", None)          # attached regardless of scope (ops.py:127)
+        w = get_variable("kernel", shape=[kernel, kernel, channels, Cin], initializer=weight_init, regularizer=reg)
+        _regularize(w, reg)
+        wk = spectral_norm(w, _shape_only=_is_meta(x)) if opt.get("conv", {}).get("sn", True) else w
+        bias = None
+        if use_bias:
+            bias = get_variable("bias", [channels], initializer=S.constant_initializer(0.0))
+        if _is_meta(x):
+            return _meta((N, H * stride, W * stride, channels))
+        return Fn.Deconv2dFn.apply(x, wk, bias, stride, pad_lo, _accumulate_into)
+
+
+def get_variable_with_custom_lr(name, shape, regularizer, lrmul):
+    """ops.py:141-146."""
+    if lrmul != 1.0:
+        raise NotImplementedError("lrmul != 1.0")
+    return get_variable(name, shape, initializer=S.truncated_normal_initializer(mean=0.0, stddev=0.02 / lrmul),
+                        regularizer=regularizer)
+
+
+def fully_connected(x, units, opt, use_bias=True, lrmul=1.0, scope='fully_0'):
+    """ops.py:148-175."""
+    with variable_scope(scope) as full_scope:
+        x = flatten(x)
+        channels = x.shape[-1]
+        reg = opt.get("fc_regularizer") if 'generator' in full_scope else None
+        w = get_variable_with_custom_lr("kernel", shape=[channels, units], regularizer=reg, lrmul=lrmul)
+        _regularize(w, reg)
+        bias = get_variable("bias", [units], initializer=S.constant_initializer(0.0)) if use_bias else None
+        wk = spectral_norm(w, _shape_only=_is_meta(x)) if opt.get("conv", {}).get("sn", True) else w
+        if _is_meta(x):
+            return _meta((x.shape[0], units))
+        return Fn.DenseFn.apply(x, wk, bias)
+
+
+def flatten(x):
+    """ops.py:177-178.  Keeps column slices as views (no copy)."""
+    if x.dim() == 2:
+        return x
+    if x.dim() == 4 and x.shape[1] == 1 and x.shape[2] == 1:
+        return x[:, 0, 0, :]
+    return x.reshape(x.shape[0], -1)
+
+
+def hw_flatten(x):
+    """ops.py:180-181."""
+    return x.reshape(x.shape[0], -1, x.shape[-1])
+
+
+##################################################################################
+# Residual-block, Self-Attention-block
+##################################################################################
+def _add(a, b):
+    if _is_meta(a):
+        return _meta(a.shape)
+    return Fn.AddFn.apply(a, b)
+
+
+def resblock(x_init, channels, opt, use_bias=True, scope='resblock'):
+    """ops.py:187-198."""
+    with variable_scope(scope):
+        with variable_scope('res1'):
+            x = conv(x_init, channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
+            if opt["bn_in_d"]:
+                x = bn(x, opt=opt)
+            x = opt["act"](x)
+        with variable_scope('res2'):
+            x = conv(x, channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
+            if opt["bn_in_d"]:
+                x = bn(x, opt=opt)
+        return _add(x, x_init)
+
+
+def upconv(x, channels, opt, use_bias=True, _accumulate_into=None):
+    """ops.py:200-218."""
+    m = opt["upsampling_method"]
+    if m == 'deconv3':
+        return deconv(x, channels, kernel=3, stride=2, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into)
+    elif m == 'deconv4':
+        return deconv(x, channels, kernel=4, stride=2, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into)
+    elif m == 'deconv6':
+        return deconv(x, channels, kernel=6, stride=2, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into)
+    elif m in ('subpixel2', 'subpixel3', 'resize_conv', 'nn'):
+        raise NotImplementedError("upsampling_method %s is outside the default hot path" % m)
+    else:
+        raise ValueError("Invalid upsampling method specified: " + str(m))
+
+
+def g_conv(x, channels, opt, use_bias=True, _accumulate_into=None):
+    """ops.py:220-230."""
+    m = opt["g_conv"]
+    if m == 'deconv3':
+        return deconv(x, channels, kernel=3, stride=1, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into)
+    elif m == 'deconv4':
+        return deconv(x, channels, kernel=4, stride=1, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into)
+    elif m == 'conv3':
+        y = conv(x, channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
+        return y if _accumulate_into is None else _add(y, _accumulate_into)
+    elif m == 'conv5':
+        y = conv(x, channels, kernel=5, stride=1, pad=2, use_bias=use_bias, opt=opt)
+        return y if _accumulate_into is None else _add(y, _accumulate_into)
+    else:
+        raise ValueError("Invalid generator convolution type specified: " + str(m))
+
+
+def resblock_up(x_init, channels, opt, use_bias=True, scope='resblock_up'):
+    """ops.py:232-248."""
+    with variable_scope(scope):
+        with variable_scope('res1'):
+            x = _bn_act(x_init, None, opt)
+            x = upconv(x, channels, use_bias=use_bias, opt=opt)
+        with variable_scope('res2'):
+            x = _bn_act(x, None, opt)
+        with variable_scope('skip'):
+            skip = upconv(x_init, channels, use_bias=use_bias, opt=opt)
+        with variable_scope('res2'):
+            x = g_conv(x, channels, use_bias=use_bias, opt=opt, _accumulate_into=skip)
+    return x
+
+
+def resblock_up_condition(x_init, z, channels, opt, use_bias=True, scope='resblock_up'):
+    """ops.py:250-266.  The skip branch is evaluated before the last main-branch deconv so the
+    residual sum is fused into that kernel's epilogue (same values, one pass less)."""
+    with variable_scope(scope):
+        with variable_scope('res1'):
+            x = _bn_act(x_init, z, opt)
+            x = upconv(x, channels, use_bias=use_bias, opt=opt)
+        with variable_scope('res2'):
+            x = _bn_act(x, z, opt)
+        with variable_scope('skip'):
+            skip = upconv(x_init, channels, use_bias=use_bias, opt=opt)
+        with variable_scope('res2'):
+            x = g_conv(x, channels, use_bias=use_bias, opt=opt, _accumulate_into=skip)
+    return x
+
+
+def downconv(x, channels, opt, use_bias=True, method=None):
+    """ops.py:269-291."""
+    if method is None:
+        method = opt["downsampling_method"]
+    if method == 'strided_conv3':
+        return conv(x, channels, kernel=3, stride=2, pad=1, use_bias=use_bias, opt=opt)
+    elif method in ('resize_conv1', 'resize_conv3', 'resize_conv35', 'pool_only', 'max_pool_only'):
+        raise NotImplementedError("downsampling_method %s is outside the default hot path" % method)
+    else:
+        raise ValueError("Invalid downsampling method specified: " + str(method))
+
+
+def resblock_down(x_init, channels, opt, use_bias=True, scope='resblock_down'):
+    """ops.py:293-313."""
+    with variable_scope(scope):
+        with variable_scope('res1'):
+            if opt["bn_in_d"]:
+                x = bn(x_init, opt=opt)
+            else:
+                x = x_init
+            x = opt["act"](x)
+            res_method = opt["downsampling_method"]
+            if res_method != 'strided_conv3':
+                res_method = 'resize_conv3'
+            x = downconv(x, channels, use_bias=use_bias, opt=opt, method=res_method)
+        with variable_scope('res2'):
+            if opt["bn_in_d"]:
+                x = bn(x, opt=opt)
+            x = opt["act"](x)
+            x = conv(x, channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
+        with variable_scope('skip'):
+            x_init = downconv(x_init, channels, use_bias=use_bias, opt=opt, method=opt["downsampling_method"])
+    return _add(x, x_init)
+
+
+def resblock_up_cond_deep(*a, **k):
+    raise NotImplementedError("--deep blocks (ops.py:317) are outside the default hot path")
+
+
+def resblock_down_deep(*a, **k):
+    raise NotImplementedError("--deep blocks (ops.py:360) are outside the default hot path")
+
+
+def clown_conv(*a, **k):
+    raise NotImplementedError("clown_conv (ops.py:403) is outside the default hot path")
+
+
+def mixed_resblock(*a, **k):
+    raise NotImplementedError("mixed_resblock (ops.py:433) is outside the default hot path")
+
+
+def self_attention(x, channels, opt, scope='self_attention'):
+    raise NotImplementedError("self_attention (ops.py:445) is never called by the reference; use self_attention_2")
+
+
+def self_attention_2(x, channels, opt, scope='self_attention'):
+    """ops.py:467-492."""
+    with variable_scope(scope):
+        use_bias = opt.get("self_attention_bias", False)
+        f = conv(x, channels // 8, kernel=1, stride=1, opt=opt, scope='f_conv', use_bias=use_bias)
+        f = max_pooling(f)
+        g = conv(x, channels // 8, kernel=1, stride=1, opt=opt, scope='g_conv', use_bias=use_bias)
+        h = conv(x, channels // 2, kernel=1, stride=1, opt=opt, scope='h_conv', use_bias=use_bias)
+        h = max_pooling(h)
+        gamma = get_variable("gamma", [1], initializer=S.constant_initializer(0.0))
+        if _is_meta(x):
+            o = _meta((x.shape[0], x.shape[1], x.shape[2], channels // 2))
+        else:
+            o = Fn.AttentionFn.apply(hw_flatten(g), hw_flatten(f), hw_flatten(h))     # softmax(g f^T) h
+            o = o.reshape(x.shape[0], x.shape[1], x.shape[2], channels // 2)
+        o = conv(o, channels, kernel=1, stride=1, opt=opt, scope='attn_conv', use_bias=use_bias)
+        if _is_meta(x):
+            return _meta(x.shape)
+        return Fn.ScaleAddFn.apply(o, gamma, x)                                          # gamma * o + x
+
+
+##################################################################################
+# Sampling
+##################################################################################
+def global_avg_pooling(x):
+    raise NotImplementedError("global_avg_pooling (ops.py:498) is not used by the default hot path")
+
+
+def global_sum_pooling(x):
+    """ops.py:503-506."""
+    if _is_meta(x):
+        return _meta((x.shape[0], x.shape[-1]))
+    return Fn.SumPoolFn.apply(x)
+
+
+def max_pooling(x):
+    """ops.py:508-510 (2x2, stride 2, 'SAME'; even H and W)."""
+    if x.shape[1] % 2 or x.shape[2] % 2:
+        raise NotImplementedError("max_pooling on odd spatial sizes")
+    if _is_meta(x):
+        return _meta((x.shape[0], x.shape[1] // 2, x.shape[2] // 2, x.shape[3]))
+    return Fn.MaxPool2Fn.apply(x)
+
+
+def avg_pooling(x):
+    raise NotImplementedError("avg_pooling (ops.py:512) is outside the default hot path")
+
+
+def up_sample(x, scale_factor=2):
+    raise NotImplementedError("up_sample (ops.py:516) is outside the default hot path")
+
+
+##################################################################################
+# Activation function
+##################################################################################
+_const_alpha = {}
+
+
+def _constant_alpha(C, value, device):
+    key = (C, float(value), str(device))
+    if key not in _const_alpha:
+        _const_alpha[key] = torch.full((C,), float(value), dtype=torch.float32, device=device)
+    return _const_alpha[key]
+
+
+def lrelu(x, alpha=0.2):
+    """ops.py:525-526."""
+    if _is_meta(x):
+        return _meta(x.shape)
+    return Fn.PReluFn.apply(x, _constant_alpha(x.shape[-1], alpha, x.device))
+
+
+def relu(x):
+    """ops.py:529-530."""
+    if _is_meta(x):
+        return _meta(x.shape)
+    return Fn.PReluFn.apply(x, _constant_alpha(x.shape[-1], 0.0, x.device))
+
+
+def prelu(x, scope=None, init_val=0.0):
+    """ops.py:532-537."""
+    with variable_scope(name_or_scope=scope, default_name="prelu"):
+        alphas = get_variable('alpha', x.shape[-1], initializer=S.constant_initializer(init_val))
+        if _is_meta(x):
+            return _meta(x.shape)
+        return Fn.PReluFn.apply(x, alphas)
+
+
+def tanh(x):
+    """ops.py:539-540."""
+    if _is_meta(x):
+        return _meta(x.shape)
+    return Fn.TanhFn.apply(x)
+
+
+##################################################################################
+# Normalization function
+##################################################################################
+def _bn_type(opt, scope):
+    type = opt.get("bn", {}).get("type", "bn")
+    if type == 'batch_norm_broken_renorm':
+        type = 'batch_norm'
+        if scope == 'batch_norm':
+            scope = 'batch_renorm'
+    return type, scope
+
+
+def bn(x, opt={}, scope='batch_norm'):
+    """ops.py:546-561."""
+    type, scope = _bn_type(opt, scope)
+    if type == 'bn' or type == 'batch_norm':
+        return batch_norm(x, opt=opt, scope=scope)
+    elif type == 'batch_renorm':
+        raise NotImplementedError("batch_renorm (ops.py:600) is outside the default hot path")
+    else:
+        raise ValueError("Unknown BN type: " + str(type))
+
+
+def cond_bn(x, z, opt={}, scope='batch_norm'):
+    """ops.py:563-578."""
+    type, scope = _bn_type(opt, scope)
+    if type == 'bn' or type == 'batch_norm':
+        return condition_batch_norm(x, z, opt=opt, scope=scope)
+    elif type == 'batch_renorm':
+        raise NotImplementedError("condition_batch_renorm (ops.py:645) is outside the default hot path")
+    else:
+        raise ValueError("Unknown BN type: " + str(type))
+
+
+def _act_alpha(act, x):
+    """Fusable activation -> (fused?, alpha tensor or None).  PReLU's variable is created under the
+    reference's default-name scope so the parameter name is unchanged."""
+    if act is prelu:
+        with variable_scope(None, default_name="prelu"):
+            return True, get_variable('alpha', x.shape[-1], initializer=S.constant_initializer(0.0))
+    if act is relu:
+        return True, (None if _is_meta(x) else _constant_alpha(x.shape[-1], 0.0, x.device))
+    return False, None
+
+
+def _bn_act(x, z, opt):
+    """(cond_)bn followed by opt['act'], fused into one apply kernel when the activation is PReLU/ReLU."""
+    fused_types = ('bn', 'batch_norm', 'batch_norm_broken_renorm')
+    if opt.get("bn", {}).get("type", "bn") in fused_types and opt["act"] in (prelu, relu):
+        type, scope = _bn_type(opt, 'batch_norm')
+        if z is None:
+            return batch_norm(x, opt=opt, scope=scope, _act=opt["act"])
+        return condition_batch_norm(x, z, opt=opt, scope=scope, _act=opt["act"])
+    x = bn(x, opt=opt) if z is None else cond_bn(x, z, opt=opt)
+    return opt["act"](x)
+
+
+def batch_norm(x, opt={}, scope='batch_norm', _act=None):
+    """ops.py:580-585: tf.layers.batch_normalization(momentum, epsilon=1e-5, training)."""
+    C = x.shape[-1]
+    with variable_scope(scope):
+        gamma = get_variable("gamma", [C], initializer=S.constant_initializer(1.0))
+        beta = get_variable("beta", [C], initializer=S.constant_initializer(0.0))
+        mm = get_variable("moving_mean", [C], initializer=S.constant_initializer(0.0), trainable=False)
+        mv = get_variable("moving_variance", [C], initializer=S.constant_initializer(1.0), trainable=False)
+    alpha = None
+    if _act is not None:
+        _, alpha = _act_alpha(_act, x)
+    if _is_meta(x):
+        return _meta(x.shape)
+    momentum = opt.get("bn", {}).get("momentum", 0.98)
+    return Fn.BnActFn.apply(x, gamma, beta, alpha, mm, mv, momentum, 1e-05, True, bool(opt["is_training"]),
+                            _run.reduce_fn, _run.world)
+
+
+def batch_renorm(x, opt={}, scope='batch_renorm'):
+    raise NotImplementedError("batch_renorm (ops.py:600) is outside the default hot path")
+
+
+def condition_batch_norm(x, z, opt={}, scope='batch_norm', _act=None):
+    """ops.py:611-643."""
+    with variable_scope(scope):
+        c = x.shape[-1]
+        decay = opt.get("bn", {}).get("momentum", 0.98)
+        epsilon = 1e-05
+        test_mean = get_variable("pop_mean", shape=[c], initializer=S.constant_initializer(0.0), trainable=False)
+        test_var = get_variable("pop_var", shape=[c], initializer=S.constant_initializer(1.0), trainable=False)
+        beta = fully_connected(z, units=c, scope='beta', opt=opt)
+        gamma = fully_connected(z, units=c, scope='gamma', opt=opt)
+    alpha = None
+    if _act is not None:
+        _, alpha = _act_alpha(_act, x)
+    if _is_meta(x):
+        return _meta(x.shape)
+    return Fn.BnActFn.apply(x, gamma, beta, alpha, test_mean, test_var, decay, epsilon, False,
+                            bool(opt["is_training"]), _run.reduce_fn, _run.world)
+
+
+def condition_batch_renorm(x, z, opt={}, scope='batch_renorm'):
+    raise NotImplementedError("condition_batch_renorm (ops.py:645) is outside the default hot path")
+
+
+def spectral_norm(w, iteration=1, _shape_only=False):
+    """ops.py:718-747.  The ``u`` variable lives next to ``w`` in the current scope; one power
+    iteration per weight per run (a second instantiation in the same run reuses the first)."""
+    if iteration != 1:
+        raise NotImplementedError("spectral_norm iteration != 1")
+    u = get_variable("u", [1, w.shape[-1]], initializer=S.random_normal_initializer(), trainable=False)
+    if _shape_only:
+        return w          # shape-propagation (manifest) mode: only the variable is registered
+    key = getattr(w, "bg_name", None)
+    if key is not None and key in _run.sn_cache:
+        cached, needs = _run.sn_cache[key]
+        if needs == (torch.is_grad_enabled() and w.requires_grad):
+            return cached
+    wn = Fn.SpectralNormFn.apply(w, u)
+    if key is not None:
+        _run.sn_cache[key] = (wn, torch.is_grad_enabled() and w.requires_grad)
+    return wn
+
+
+##################################################################################
+# Loss function
+##################################################################################
+def discriminator_loss(loss_func, real, fake, flood_level=0):
+    """ops.py:753-797 ('hinge' branch)."""
+    if loss_func != 'hinge':
+        raise NotImplementedError("discriminator_loss('%s'): only --gan_type hinge is on the hot path" % loss_func)
+    return Fn.HingeDLossFn.apply(real, fake, flood_level, _run.reduce_fn, _run.world)
+
+
+def generator_loss(loss_func, fake, real, flood_level=0):
+    """ops.py:799-840 ('hinge' branch)."""
+    if loss_func != 'hinge':
+        raise NotImplementedError("generator_loss('%s'): only --gan_type hinge is on the hot path" % loss_func)
+    return Fn.HingeGLossFn.apply(fake, flood_level, _run.reduce_fn, _run.world)
+
+
+def glu(x, opt=None):
+    raise NotImplementedError("glu (ops.py:842) is outside the default hot path")
+
+
+def flood_loss(loss, flood_level):
+    """ops.py:847-848 (applied inside the hinge kernels; provided for API parity on host scalars)."""
+    return abs(loss - flood_level) + flood_level

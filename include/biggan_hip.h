@@ -1,0 +1,220 @@
+/* biggan_hip.h - C ABI of libbiggan_hip.so: the MI355X (gfx950) kernels behind the BigGAN
+ * training-step hot path of david-jk/BigGAN-Tensorflow.
+ *
+ * The reference has no FFI: its operator layer (ops.py, DiffAugment_tf.py) lowers to stock
+ * TensorFlow ops.  Each entry point below names the reference call site whose arithmetic it
+ * replaces (file:line relative to the reference repository).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensor storage); the library
+ *     never allocates, frees or retains memory and never synchronises the device;
+ *   - every call is asynchronous on the caller-supplied HIP stream (void* = hipStream_t) and is
+ *     safe to capture into a hipGraph;
+ *   - tensors are NHWC fp32, conv kernels HWIO [k,k,Cin,Cout], transposed-conv kernels
+ *     [k,k,Cout,Cin] (the reference's variable layouts, ops.py:88,127);
+ *   - return value 0 = success; non-zero = error, message in bg_last_error() (thread-local);
+ *   - scratch memory is passed in by the caller, sized by the matching *_workspace_bytes().
+ */
+#ifndef BIGGAN_HIP_H
+#define BIGGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BG_ABI_VERSION 1
+
+enum { BG_OK = 0, BG_ERR_ARG = 1, BG_ERR_LAUNCH = 2, BG_ERR_UNSUPPORTED = 3 };
+enum { BG_PAD_REFLECT = 0, BG_PAD_ZERO = 1 };
+
+int         bg_abi_version(void);
+const char* bg_last_error(void);
+/* "gfx950" - the only code object in the library */
+const char* bg_target_arch(void);
+
+/* --------------------------------------------------------------------------------------------
+ * Convolution geometry shared by conv / transposed conv (ops.py:49-139).
+ *   conv   : x[N,H,W,Cin]  -> y[N,Ho,Wo,Cout],  Ho = (H + pad_lo + pad_hi - k)/stride + 1
+ *   deconv : x[N,H,W,Cin]  -> y[N,Ho,Wo,Cout],  Ho = stride*H ('SAME'), pad_lo = TF's low crop
+ * ------------------------------------------------------------------------------------------ */
+typedef struct BgConvDesc {
+    int32_t N, H, W, Cin;      /* input  */
+    int32_t Ho, Wo, Cout;      /* output */
+    int32_t k, stride;
+    int32_t pad_lo;            /* low padding (conv) / low crop (deconv)            */
+    int32_t pad_mode;          /* BG_PAD_REFLECT (tf.pad REFLECT + VALID, ops.py:82) or BG_PAD_ZERO */
+} BgConvDesc;
+
+/* tf.nn.conv2d (+ reflect tf.pad, + bias_add)                       ops.py:82,94-98
+ *   y = alpha * conv(x, w) [+ bias] [+ y if accumulate]; alpha_dev (nullable) is a device scalar. */
+int bg_conv2d_fwd  (const BgConvDesc*, const float* x, const float* w, const float* bias,
+                    const float* alpha_dev, float* y, int accumulate, void* stream);
+/* gradient of the above w.r.t. x (reflect padding folded back)      autodiff of ops.py:82,94 */
+int bg_conv2d_dgrad(const BgConvDesc*, const float* dy, const float* w, const float* alpha_dev,
+                    float* dx, int accumulate, void* stream);
+/* gradient w.r.t. w: dw[k,k,Cin,Cout]; ws from bg_conv2d_wgrad_workspace_bytes */
+size_t bg_conv2d_wgrad_workspace_bytes(const BgConvDesc*);
+int bg_conv2d_wgrad(const BgConvDesc*, const float* x, const float* dy, float* dw,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* tf.nn.conv2d_transpose(SAME) (+ bias_add)                          ops.py:127-132 */
+int bg_deconv2d_fwd  (const BgConvDesc*, const float* x, const float* w, const float* bias,
+                      const float* alpha_dev, float* y, int accumulate, void* stream);
+int bg_deconv2d_dgrad(const BgConvDesc*, const float* dy, const float* w, const float* alpha_dev,
+                      float* dx, int accumulate, void* stream);
+size_t bg_deconv2d_wgrad_workspace_bytes(const BgConvDesc*);
+int bg_deconv2d_wgrad(const BgConvDesc*, const float* x, const float* dy, float* dw,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Plain (batched) matrix products: tf.matmul call sites ops.py:163-165 (dense), 481,485
+ * (attention), utils.py:198,222 (Gram matrix of the regulariser).
+ *   C[b] = alpha * op(A[b]) * op(B[b]) (+ bias[n]) (+ C[b] if accumulate), row-major, fp32.
+ *   transA: A stored [K,M] (lda = M-stride), transB: B stored [N,K].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct BgGemmDesc {
+    int32_t M, N, K;
+    int32_t transA, transB;
+    int32_t lda, ldb, ldc;
+    int32_t batch;
+    int64_t strideA, strideB, strideC;   /* elements between batch items */
+} BgGemmDesc;
+size_t bg_gemm_workspace_bytes(const BgGemmDesc*);
+int bg_gemm(const BgGemmDesc*, const float* A, const float* B, const float* bias,
+            const float* alpha_dev, float* C, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Spectral norm, one power iteration (ops.py:718-747).  W is [rows, cols] (= reshape(w,[-1,last])).
+ *   v = l2n(u W^T), u_out = l2n(v W), sigma = |v W|, w_norm = W / sigma.
+ *   l2n(t) = t * rsqrt(max(sum t^2, 1e-12)).  scratch: (rows + cols + 4) floats.
+ * bwd: dW = (G - <G, w_norm> v^T u_out) / sigma  (u_out, v stop-gradient, ops.py:738-739).
+ * ------------------------------------------------------------------------------------------ */
+size_t bg_spectral_norm_workspace_bytes(int rows, int cols);
+int bg_spectral_norm_fwd(const float* w, const float* u_in, float* u_out, float* v_out,
+                         float* sigma_out, float* w_norm, int rows, int cols,
+                         void* ws, size_t ws_bytes, void* stream);
+int bg_spectral_norm_bwd(const float* g_wnorm, const float* w_norm, const float* u_hat,
+                         const float* v_hat, const float* sigma, float* dw, int rows, int cols,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Batch statistics + (conditional) batch-norm + PReLU (ops.py:532-537, 580-585, 611-643).
+ *   x [N,HW,C].  stats: sums[0:C] = sum x, sums[C:2C] = sum x^2 over N*HW (fp32; caller zeroes or
+ *   all-reduces them for cross-replica BN), then bg_bn_finalize turns sums into mean / rstd
+ *   (biased variance, eps) and updates the moving statistics.
+ *   apply: y = act((x - mean) * rstd * gamma + beta), gamma/beta per sample [N,C] (per_sample=1,
+ *   condition_batch_norm) or per channel [C] (tf.layers.batch_normalization);
+ *   act = PReLU with per-channel alpha when alpha != NULL (ops.py:535-537), identity otherwise.
+ * ------------------------------------------------------------------------------------------ */
+int bg_bn_stats(const float* x, float* sums, int64_t rows, int C, void* stream);
+int bg_bn_finalize(const float* sums, double count, float eps, float momentum, int unbiased_moving_var,
+                   float* mean, float* rstd, float* moving_mean, float* moving_var, int C, void* stream);
+int bg_bn_apply_act_fwd(const float* x, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, int per_sample,
+                        const float* alpha, float* y, int N, int HW, int C, void* stream);
+/* backward, pass 1: per-(sample,channel) reductions
+ *   part[0][n][c] = sum_hw g, part[1][n][c] = sum_hw g * xhat, part[2][n][c] = sum_hw dy * min(pre,0)
+ *   where pre = xhat*gamma+beta, g = dy * act'(pre).            part is [3,N,C] fp32 */
+int bg_bn_apply_act_bwd_reduce(const float* x, const float* dy, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, int per_sample,
+                               const float* alpha, float* part, int N, int HW, int C, void* stream);
+/* backward, pass 2: dx = rstd * (g*gamma - m1 - xhat * m2), m1 = mean(g*gamma), m2 = mean(g*gamma*xhat)
+ *   given as per-channel device vectors cm[0:C] = m1, cm[C:2C] = m2 (caller reduces part over N,
+ *   and across ranks for cross-replica BN). */
+int bg_bn_apply_act_bwd_dx(const float* x, const float* dy, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int per_sample,
+                           const float* alpha, const float* cm, float* dx,
+                           int N, int HW, int C, void* stream);
+/* reduce part[3,N,C] -> dgamma/dbeta (per sample: copies; per channel: sums over N), dalpha[C],
+ *   cm[2C] = (sum_n gamma_n * part0_n, sum_n gamma_n * part1_n) / count */
+int bg_bn_bwd_finalize(const float* part, const float* gamma, int per_sample, double count,
+                       float* dgamma, float* dbeta, float* dalpha, float* cm, int N, int C, void* stream);
+
+/* stand-alone PReLU (ops.py:532-537): y = x>0 ? x : alpha_c*x ; bwd returns dx and per-channel
+ * partial dalpha accumulated with atomics into dalpha[C] (caller zeroes). */
+int bg_prelu_fwd(const float* x, const float* alpha, float* y, int64_t rows, int C, void* stream);
+int bg_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx, float* dalpha,
+                 int64_t rows, int C, void* stream);
+
+/* tf.layers.max_pooling2d(2,2,'SAME') on even H,W (ops.py:508-510); bwd routes to the first max */
+int bg_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int bg_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+
+/* tf.nn.softmax over the last axis (ops.py:483): rows x cols, in place allowed; bwd: ds = p*(dp - sum(dp*p)) */
+int bg_softmax_fwd(const float* s, float* p, int64_t rows, int cols, void* stream);
+int bg_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, int cols, void* stream);
+
+/* tf.reduce_sum(x,[1,2]) (ops.py:503-506) and its gradient (broadcast) */
+int bg_sum_pool_fwd(const float* x, float* y, int N, int HW, int C, void* stream);
+int bg_sum_pool_bwd(const float* dy, float* dx, int N, int HW, int C, void* stream);
+
+/* y = a*x + b*y elementwise family used by residual adds, gamma*o + x (ops.py:490), tanh (ops.py:539) */
+int bg_axpby(const float* x, float a, float* y, float b, int64_t n, void* stream);
+int bg_scale_add(const float* o, const float* gamma_dev, const float* x, float* y, int64_t n, void* stream);
+int bg_dot(const float* a, const float* b, float* out_accum, int64_t n, void* stream);   /* out += <a,b> */
+int bg_scale_dev(const float* x, const float* s_dev, float* y, int64_t n, void* stream);  /* y = s*x, s a device scalar */
+int bg_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
+int bg_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
+int bg_bias_grad(const float* dy, float* db, int64_t rows, int C, void* stream);         /* db[c] = sum_rows dy */
+
+/* --------------------------------------------------------------------------------------------
+ * DiffAugment 'color,translation,cutout' (DiffAugment_tf.py:8-73), x [N,S,S,C] fp32.
+ *   policy bit 0 = color, 1 = translation, 2 = cutout.  Draws are explicit device arrays:
+ *   u_b,u_s,u_c float[N] in [0,1); t_x,t_y int32[N] in [-shift,shift]; o_x,o_y int32[N].
+ *   mean_ws: N floats scratch (per-sample mean for rand_contrast).  Integer index math is
+ *   bit-exact with DiffAugment_tf.py:40-66.
+ * ------------------------------------------------------------------------------------------ */
+int bg_diffaugment_fwd(const float* x, float* y, const float* u_b, const float* u_s, const float* u_c,
+                       const int32_t* t_x, const int32_t* t_y, const int32_t* o_x, const int32_t* o_y,
+                       int N, int S, int C, int policy, float* mean_ws, void* stream);
+int bg_diffaugment_bwd(const float* dy, float* dx, const float* u_s, const float* u_c,
+                       const int32_t* t_x, const int32_t* t_y, const int32_t* o_x, const int32_t* o_y,
+                       int N, int S, int C, int policy, float* mean_ws, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Hinge losses with flood (ops.py:788-797, 832-840, 847-848).
+ *   sums: device float[2] accumulators (caller zeroes; all-reduced across ranks for DP):
+ *     D: sums[0] += sum relu(1-real), sums[1] += sum relu(1+fake);   G: sums[0] += sum fake
+ *   grad kernels read the (global) sums, n_global = global batch, and write the flooded loss
+ *   (loss_out[0]) and d(loss)/d(logit).
+ * ------------------------------------------------------------------------------------------ */
+int bg_hinge_d_sums(const float* real, const float* fake, float* sums, int n, void* stream);
+int bg_hinge_d_grad(const float* real, const float* fake, const float* sums, double n_global, float flood,
+                    float* d_real, float* d_fake, float* loss_out, int n, void* stream);
+int bg_hinge_g_sums(const float* fake, float* sums, int n, void* stream);
+int bg_hinge_g_grad(const float* sums, double n_global, float flood, float* d_fake, float* loss_out,
+                    int n, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Orthogonal-cosine regulariser (utils.py:180-235) from the Gram matrix A = W^T W [c,c]
+ * (computed with bg_gemm), using R[i,j] = (sum_k Ahat[i,k] - Ahat[i,j]) / sqrt(c-1):
+ *   fwd: loss_accum[0] += scale/2 * sum R^2 ; bwd: dA (so that dW = W (dA + dA^T), via bg_gemm).
+ * ------------------------------------------------------------------------------------------ */
+int bg_ortho_cosine_fwd_bwd(const float* A, float scale, float* loss_accum, float* dA, int c, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * TF AdamOptimizer (+ MovingAverageOptimizer shadow) over a flat parameter arena (BigGAN.py:923-927):
+ *   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t * m / (sqrt(v) + eps);
+ *   lr_t = lr sqrt(1-b2^t)/(1-b1^t) computed by the caller; ema (nullable) = d*ema + (1-d)*p.
+ *   grad_scale multiplies g first (1/world_size for summed all-reduce).
+ * ------------------------------------------------------------------------------------------ */
+int bg_adam_tf_ema_step(float* p, const float* g, float* m, float* v, float* ema,
+                        float lr_t, float b1, float b2, float eps, float ema_decay, float grad_scale,
+                        int64_t n, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Optional per-kernel timing for bench.py's roofline leg: when enabled, every MFMA GEMM launch
+ * (conv / deconv / gemm families) is bracketed by hipEvents on its stream.
+ * bg_prof_collect synchronises the events and returns totals since the last reset.
+ * ------------------------------------------------------------------------------------------ */
+void bg_prof_enable(int on);
+void bg_prof_reset(void);
+int  bg_prof_collect(double* total_ms, double* total_flops, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIGGAN_HIP_H */

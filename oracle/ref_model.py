@@ -178,10 +178,10 @@ def discriminator(vs, cfg, x):
     feat = R.global_sum_pooling(x)                                          # :671
     out = {}
     out["real"] = R.fully_connected(vs, D + "/D_logit", feat, 1, opt,
-                                    sn=cfg.sn and cfg.d_compat_use_sn_in_critic_output)   # :681-682
+                                    sn=cfg.d_compat_use_sn_in_critic_output)   # :681-682, 1482-1487
     if cfg.n_labels > 0:                                                    # :689-701
         out["cls"] = R.fully_connected(vs, D + "/DC_logit", feat, cfg.n_labels, opt,
-                                       sn=cfg.sn and cfg.d_compat_use_sn_in_classification)
+                                       sn=cfg.d_compat_use_sn_in_classification)
     return out
 
 

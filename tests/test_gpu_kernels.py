@@ -1,0 +1,470 @@
+"""GPU parity tests: every HIP kernel family, called through the C ABI, against the CPU oracle on
+the same seeded inputs.  Tolerances are stated per test: bit-exact for DiffAugment's integer
+indexing, fp32 accumulation-order noise (<= 2e-5 relative L2) for the MFMA GEMM families."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import kat
+from oracle import ref_ops as R
+from tests.common import rel_err, t2n
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def _fn():
+    import biggan_tensorflow_amd  # noqa: F401
+    from biggan_tensorflow_amd import functional as Fn
+    return Fn
+
+
+def _hip():
+    from biggan_tensorflow_amd import hip
+    return hip
+
+
+def cu(a, grad=False):
+    t = torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda")
+    if grad:
+        t.requires_grad_(True)
+    return t
+
+
+def test_library_loaded_and_arch():
+    hip = _hip()
+    L = hip.lib()
+    assert L.bg_abi_version() == 1
+    assert L.bg_target_arch() == b"gfx950"
+    with pytest.raises(RuntimeError):
+        hip.f32(torch.zeros(4))          # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------------------------------
+# conv (ops.py:49-113)
+# ------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # N, H, Cin, Cout, k, s, pad, bias
+    (2, 8, 8, 16, 3, 1, 1, False),
+    (2, 8, 8, 16, 3, 2, 1, False),
+    (3, 16, 3, 8, 3, 2, 1, False),      # image layer: Cin = 3 (scalar loads)
+    (2, 16, 16, 3, 3, 1, 1, False),     # G_logit: Cout = 3
+    (2, 8, 12, 6, 1, 1, 0, True),       # SA 1x1 conv with bias, C % 4 != 0 on the output
+    (1, 4, 32, 32, 3, 1, 1, True),      # 4x4 map: every pixel touches the reflect border
+    (5, 12, 20, 72, 3, 2, 1, True),     # ragged tiles in M, N and K
+    (2, 32, 64, 128, 3, 1, 1, False),   # 128x128 tile path
+]
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,k,s,pad,use_bias", CONV_CASES)
+def test_conv2d_fwd_bwd(N, H, Cin, Cout, k, s, pad, use_bias):
+    Fn, hip = _fn(), _hip()
+    rng = np.random.default_rng(N * 1000 + H + Cin + Cout + k + s)
+    x = rng.standard_normal((N, H, H, Cin))
+    w = rng.standard_normal((k, k, Cin, Cout)) * 0.2
+    b = rng.standard_normal(Cout) if use_bias else None
+    # oracle (float64)
+    xt = torch.tensor(x, requires_grad=True)
+    wt = torch.tensor(w, requires_grad=True)
+    xin = xt.permute(0, 3, 1, 2)
+    if pad:
+        xin = F.pad(xin, (pad, pad, pad, pad), mode="reflect")
+    yr = F.conv2d(xin, wt.permute(3, 2, 0, 1), stride=s).permute(0, 2, 3, 1)
+    bt = None
+    if use_bias:
+        bt = torch.tensor(b, requires_grad=True)
+        yr = yr + bt
+    g = rng.standard_normal(tuple(yr.shape))
+    yr.backward(torch.tensor(g))
+    Ho = yr.shape[1]
+    # HIP
+    xc, wc = cu(x, True), cu(w, True)
+    bc = cu(b, True) if use_bias else None
+    y = Fn.Conv2dFn.apply(xc, wc, bc, s, pad, Ho, Ho, hip.PAD_REFLECT)
+    y.backward(cu(g))
+    assert rel_err(t2n(y), yr.detach().numpy()) < TOL
+    assert rel_err(t2n(xc.grad), xt.grad.numpy()) < TOL
+    assert rel_err(t2n(wc.grad), wt.grad.numpy()) < TOL
+    if use_bias:
+        assert rel_err(t2n(bc.grad), bt.grad.numpy()) < TOL
+
+
+def test_conv_matches_direct_loop_kat():
+    """Alignment KAT against the direct-loop TF semantics (reflect 1+1, k3 s2, even H)."""
+    Fn, hip = _fn(), _hip()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 8, 8, 5))
+    w = rng.standard_normal((3, 3, 5, 7))
+    ref = kat.conv2d_valid(kat.reflect_pad(x, 1, 1), w, 2)
+    y = Fn.Conv2dFn.apply(cu(x), cu(w), None, 2, 1, 4, 4, hip.PAD_REFLECT)
+    assert rel_err(t2n(y), ref) < TOL
+
+
+def test_conv_zero_padding_same():
+    Fn, hip = _fn(), _hip()
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 9, 9, 8))
+    w = rng.standard_normal((3, 3, 8, 8))
+    ref = kat.conv2d_valid(np.pad(x, [(0, 0), (1, 1), (1, 1), (0, 0)]), w, 1)
+    xc, wc = cu(x, True), cu(w, True)
+    y = Fn.Conv2dFn.apply(xc, wc, None, 1, 1, 9, 9, hip.PAD_ZERO)
+    assert rel_err(t2n(y), ref) < TOL
+    g = rng.standard_normal(ref.shape)
+    y.backward(cu(g))
+    xt = torch.tensor(x, requires_grad=True)
+    wt = torch.tensor(w, requires_grad=True)
+    yr = F.conv2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    yr.backward(torch.tensor(g))
+    assert rel_err(t2n(xc.grad), xt.grad.numpy()) < TOL
+    assert rel_err(t2n(wc.grad), wt.grad.numpy()) < TOL
+
+
+# ------------------------------------------------------------------------------------------
+# transposed conv (ops.py:116-139)
+# ------------------------------------------------------------------------------------------
+DECONV_CASES = [
+    # N, H, Cin, Cout, k, s
+    (2, 4, 16, 8, 4, 2),
+    (2, 4, 16, 8, 3, 1),
+    (3, 8, 24, 40, 4, 2),     # ragged tiles
+    (1, 16, 8, 8, 3, 1),
+    (2, 8, 6, 10, 4, 2),      # C % 4 != 0
+    (2, 16, 128, 64, 4, 2),   # big-tile path
+    (2, 16, 64, 128, 3, 1),
+]
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,k,s", DECONV_CASES)
+def test_deconv2d_fwd_bwd(N, H, Cin, Cout, k, s):
+    Fn = _fn()
+    rng = np.random.default_rng(N * 100 + H + Cin + Cout + k)
+    x = rng.standard_normal((N, H, H, Cin))
+    w = rng.standard_normal((k, k, Cout, Cin)) * 0.2
+    b = rng.standard_normal(Cout)
+    xt = torch.tensor(x, requires_grad=True)
+    wt = torch.tensor(w, requires_grad=True)
+    bt = torch.tensor(b, requires_grad=True)
+    yr = F.conv_transpose2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), stride=s, padding=1).permute(0, 2, 3, 1) + bt
+    g = rng.standard_normal(tuple(yr.shape))
+    yr.backward(torch.tensor(g))
+    xc, wc, bc = cu(x, True), cu(w, True), cu(b, True)
+    y = Fn.Deconv2dFn.apply(xc, wc, bc, s, 1, None)
+    y.backward(cu(g))
+    assert tuple(y.shape) == (N, s * H, s * H, Cout)
+    assert rel_err(t2n(y), yr.detach().numpy()) < TOL
+    assert rel_err(t2n(xc.grad), xt.grad.numpy()) < TOL
+    assert rel_err(t2n(wc.grad), wt.grad.numpy()) < TOL
+    assert rel_err(t2n(bc.grad), bt.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("k,s", [(4, 2), (3, 1)])
+def test_deconv_matches_tf_gradient_definition(k, s):
+    """KAT: tf.nn.conv2d_transpose(SAME) as the input-gradient of a SAME conv (no flip, low crop 1)."""
+    Fn = _fn()
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((2, 5, 5, 4))
+    w = rng.standard_normal((k, k, 3, 4))
+    ref = kat.conv2d_transpose_same(x, w, s)
+    y = Fn.Deconv2dFn.apply(cu(x), cu(w), None, s, 1, None)
+    assert rel_err(t2n(y), ref) < TOL
+
+
+def test_deconv_accumulate_into_epilogue():
+    Fn = _fn()
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 4, 4, 8))
+    w = rng.standard_normal((3, 3, 8, 8))
+    base = rng.standard_normal((2, 4, 4, 8))
+    xc, wc, bc = cu(x, True), cu(w, True), cu(base, True)
+    y = Fn.Deconv2dFn.apply(xc, wc, None, 1, 1, bc * 1.0)
+    ref = kat.conv2d_transpose_same(x, w, 1) + base
+    assert rel_err(t2n(y), ref) < TOL
+    y.sum().backward()
+    assert np.allclose(t2n(bc.grad), 1.0)
+
+
+# ------------------------------------------------------------------------------------------
+# dense / attention (ops.py:148-175, 481-485)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N", [(16, 96, 184), (16, 184, 1024), (8, 32, 64), (64, 128, 1), (5, 7, 3)])
+def test_dense_fwd_bwd(M, K, N):
+    Fn = _fn()
+    rng = np.random.default_rng(M + K + N)
+    x, w, b = rng.standard_normal((M, K)), rng.standard_normal((K, N)) * 0.1, rng.standard_normal(N)
+    xt, wt, bt = (torch.tensor(a, requires_grad=True) for a in (x, w, b))
+    yr = xt @ wt + bt
+    g = rng.standard_normal((M, N))
+    yr.backward(torch.tensor(g))
+    xc, wc, bc = cu(x, True), cu(w, True), cu(b, True)
+    y = Fn.DenseFn.apply(xc, wc, bc)
+    y.backward(cu(g))
+    assert rel_err(t2n(y), yr.detach().numpy()) < TOL
+    assert rel_err(t2n(xc.grad), xt.grad.numpy()) < TOL
+    assert rel_err(t2n(wc.grad), wt.grad.numpy()) < TOL
+    assert rel_err(t2n(bc.grad), bt.grad.numpy()) < TOL
+
+
+def test_dense_on_column_slice_without_copy():
+    Fn = _fn()
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal((8, 256))
+    w = rng.standard_normal((32, 48)) * 0.1
+    zc = cu(z)
+    y = Fn.DenseFn.apply(zc[:, 96:128], cu(w), None)
+    assert rel_err(t2n(y), z[:, 96:128] @ w) < TOL
+
+
+@pytest.mark.parametrize("B,N,Nk,dq,dv", [(2, 256, 64, 2, 8), (3, 1024, 256, 8, 32), (1, 4096, 1024, 16, 64)])
+def test_attention_fwd_bwd(B, N, Nk, dq, dv):
+    Fn = _fn()
+    rng = np.random.default_rng(N + dq)
+    q, k, v = rng.standard_normal((B, N, dq)), rng.standard_normal((B, Nk, dq)), rng.standard_normal((B, Nk, dv))
+    qt, kt, vt = (torch.tensor(a, requires_grad=True) for a in (q, k, v))
+    o_ref = torch.softmax(qt @ kt.transpose(1, 2), -1) @ vt
+    g = rng.standard_normal((B, N, dv))
+    o_ref.backward(torch.tensor(g))
+    qc, kc, vc = cu(q, True), cu(k, True), cu(v, True)
+    o = Fn.AttentionFn.apply(qc, kc, vc)
+    o.backward(cu(g))
+    assert rel_err(t2n(o), o_ref.detach().numpy()) < TOL
+    assert rel_err(t2n(qc.grad), qt.grad.numpy()) < 5e-5
+    assert rel_err(t2n(kc.grad), kt.grad.numpy()) < 5e-5
+    assert rel_err(t2n(vc.grad), vt.grad.numpy()) < TOL
+
+
+# ------------------------------------------------------------------------------------------
+# spectral norm (ops.py:718-747)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(3, 3, 16, 32), (32, 64), (4, 4, 8, 24), (184, 1024), (3, 3, 8, 3), (16, 1)])
+def test_spectral_norm_fwd_bwd(shape):
+    Fn = _fn()
+    rng = np.random.default_rng(sum(shape))
+    w = rng.standard_normal(shape) * 0.1
+    cols = shape[-1]
+    u = rng.standard_normal((1, cols))
+    W = torch.tensor(w).reshape(-1, cols)
+    ut = torch.tensor(u)
+    v_hat = R.l2_normalize(ut @ W.t())
+    u_hat = R.l2_normalize(v_hat @ W)
+    sigma = (v_hat @ W @ u_hat.t()).item()
+    wc = cu(w, True)
+    uc = cu(u)
+    wn = Fn.SpectralNormFn.apply(wc, uc)
+    assert rel_err(t2n(wn), w / sigma) < TOL
+    assert rel_err(t2n(uc), u_hat.numpy()) < TOL            # u <- u_hat in place (ops.py:743)
+    G = rng.standard_normal(shape)
+    wn.backward(cu(G))
+    Gm = torch.tensor(G).reshape(-1, cols)
+    exp = (Gm - (Gm * (W / sigma)).sum() * (v_hat.t() @ u_hat)) / sigma
+    assert rel_err(t2n(wc.grad).reshape(-1, cols), exp.numpy()) < 5e-5
+
+
+# ------------------------------------------------------------------------------------------
+# batch norm + PReLU (ops.py:532-537, 580-585, 611-643)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,C,per_sample,with_alpha", [
+    (4, 8, 16, True, True), (3, 4, 40, True, False), (2, 16, 8, False, True), (5, 2, 1024, True, True),
+    (2, 4, 6, False, False)])
+def test_bn_act_fwd_bwd(N, H, C, per_sample, with_alpha):
+    Fn = _fn()
+    rng = np.random.default_rng(N + H + C)
+    x = rng.standard_normal((N, H, H, C)) * 1.5 + 0.3
+    gshape = (N, C) if per_sample else (C,)
+    gamma, beta = rng.standard_normal(gshape), rng.standard_normal(gshape)
+    alpha = rng.uniform(0.05, 0.4, C) if with_alpha else None
+    mm0, mv0 = rng.standard_normal(C), rng.uniform(0.5, 2, C)
+    xt, gt, bt = (torch.tensor(a, requires_grad=True) for a in (x, gamma, beta))
+    at = torch.tensor(alpha, requires_grad=True) if with_alpha else None
+    mean = xt.mean(dim=(0, 1, 2))
+    var = ((xt - mean) ** 2).mean(dim=(0, 1, 2))
+    gb = gt.reshape(-1, 1, 1, C) if per_sample else gt
+    bb = bt.reshape(-1, 1, 1, C) if per_sample else bt
+    inv = torch.rsqrt(var + 1e-5) * gb
+    pre = xt * inv + (bb - mean * inv)
+    yr = torch.relu(pre) + at * (pre - pre.abs()) * 0.5 if with_alpha else pre
+    g = rng.standard_normal(x.shape)
+    yr.backward(torch.tensor(g))
+    xc, gc, bc = cu(x, True), cu(gamma, True), cu(beta, True)
+    ac = cu(alpha, True) if with_alpha else None
+    mm, mv = cu(mm0), cu(mv0)
+    y = Fn.BnActFn.apply(xc, gc, bc, ac, mm, mv, 0.98, 1e-5, not per_sample, True, None, 1)
+    y.backward(cu(g))
+    assert rel_err(t2n(y), yr.detach().numpy()) < TOL
+    assert rel_err(t2n(xc.grad), xt.grad.numpy()) < 1e-4
+    assert rel_err(t2n(gc.grad), gt.grad.numpy()) < 5e-5
+    assert rel_err(t2n(bc.grad), bt.grad.numpy()) < 5e-5
+    if with_alpha:
+        assert rel_err(t2n(ac.grad), at.grad.numpy()) < 5e-5
+    n = N * H * H
+    vfac = n / (n - 1) if not per_sample else 1.0          # tf.layers BN: Bessel-corrected moving variance
+    assert rel_err(t2n(mm), mm0 * 0.98 + mean.detach().numpy() * 0.02) < TOL
+    assert rel_err(t2n(mv), mv0 * 0.98 + var.detach().numpy() * vfac * 0.02) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 3), (4, 4, 4, 64), (7, 33)])
+def test_prelu(shape):
+    Fn = _fn()
+    rng = np.random.default_rng(len(shape))
+    x = rng.standard_normal(shape)
+    a = rng.uniform(0.05, 0.3, shape[-1])
+    xt, at = torch.tensor(x, requires_grad=True), torch.tensor(a, requires_grad=True)
+    yr = torch.relu(xt) + at * (xt - xt.abs()) * 0.5
+    g = rng.standard_normal(shape)
+    yr.backward(torch.tensor(g))
+    xc, ac = cu(x, True), cu(a, True)
+    y = Fn.PReluFn.apply(xc, ac)
+    y.backward(cu(g))
+    assert rel_err(t2n(y), yr.detach().numpy()) < 1e-6
+    assert rel_err(t2n(xc.grad), xt.grad.numpy()) < 1e-6
+    assert rel_err(t2n(ac.grad), at.grad.numpy()) < 5e-5
+
+
+def test_pooling_tanh_scaleadd():
+    Fn = _fn()
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 8, 8, 12))
+    xt = torch.tensor(x, requires_grad=True)
+    yr = F.max_pool2d(xt.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    g = rng.standard_normal(tuple(yr.shape))
+    yr.backward(torch.tensor(g))
+    xc = cu(x, True)
+    y = Fn.MaxPool2Fn.apply(xc)
+    y.backward(cu(g))
+    assert np.array_equal(t2n(y), yr.detach().numpy().astype(np.float32))
+    assert np.array_equal(t2n(xc.grad), xt.grad.numpy().astype(np.float32))
+    # global sum pool
+    xc2 = cu(x, True)
+    s = Fn.SumPoolFn.apply(xc2)
+    assert rel_err(t2n(s), x.sum((1, 2))) < 1e-6
+    s.backward(cu(np.ones((2, 12))))
+    assert np.allclose(t2n(xc2.grad), 1.0)
+    # tanh
+    xc3 = cu(x, True)
+    t = Fn.TanhFn.apply(xc3)
+    t.backward(cu(g_ := rng.standard_normal(x.shape)))
+    assert rel_err(t2n(t), np.tanh(x)) < 1e-6
+    assert rel_err(t2n(xc3.grad), g_ * (1 - np.tanh(x) ** 2)) < 1e-5
+    # gamma * o + x
+    o = rng.standard_normal(x.shape)
+    oc, gc, xc4 = cu(o, True), cu([0.37], True), cu(x, True)
+    r = Fn.ScaleAddFn.apply(oc, gc, xc4)
+    r.backward(cu(g_))
+    assert rel_err(t2n(r), 0.37 * o + x) < 1e-6
+    assert rel_err(t2n(oc.grad), 0.37 * g_) < 1e-6
+    assert rel_err(t2n(gc.grad), [(g_ * o).sum()]) < 5e-5
+    assert rel_err(t2n(xc4.grad), g_) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------
+# DiffAugment (DiffAugment_tf.py)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S", [8, 32, 64, 128])
+def test_diffaugment_translation_cutout_bit_exact(S):
+    from biggan_tensorflow_amd.DiffAugment import DiffAugment, draws_to_device
+    rng = np.random.default_rng(S)
+    B = 6
+    x = rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32)
+    d = R.draw_diffaugment(rng, B, S)
+    shift, cs, off_max = R.diffaugment_params(S)
+    d["t_x"][0], d["t_y"][0] = -shift, shift            # extreme draws (edge cases)
+    d["t_x"][1], d["t_y"][1] = shift, -shift
+    d["o_x"][2], d["o_y"][2] = 0, off_max - 1
+    d["o_x"][3], d["o_y"][3] = off_max - 1, 0
+    lit = R.cutout_literal(R.translation_literal(x, d["t_x"], d["t_y"]), d["o_x"], d["o_y"])
+    y = DiffAugment(cu(x), "translation,cutout", draws=draws_to_device(d, "cuda"))
+    assert np.array_equal(t2n(y), lit)                   # bit-exact integer indexing
+    y1 = DiffAugment(cu(x), "translation", draws=draws_to_device(d, "cuda"))
+    assert np.array_equal(t2n(y1), R.translation_literal(x, d["t_x"], d["t_y"]))
+    y2 = DiffAugment(cu(x), "cutout", draws=draws_to_device(d, "cuda"))
+    assert np.array_equal(t2n(y2), R.cutout_literal(x, d["o_x"], d["o_y"]))
+
+
+@pytest.mark.parametrize("policy", ["color,translation,cutout", "color", "color,cutout"])
+def test_diffaugment_full_policy_fwd_bwd(policy):
+    from biggan_tensorflow_amd.DiffAugment import DiffAugment, draws_to_device
+    rng = np.random.default_rng(11)
+    B, S = 4, 16
+    x = rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32)
+    d = R.draw_diffaugment(rng, B, S)
+    xt = torch.tensor(x.astype(np.float64), requires_grad=True)
+    yr = R.diffaugment(xt, d, policy)
+    g = rng.standard_normal(x.shape)
+    yr.backward(torch.tensor(g))
+    xc = cu(x, True)
+    y = DiffAugment(xc, policy, draws=draws_to_device(d, "cuda"))
+    y.backward(cu(g))
+    assert np.abs(t2n(y) - yr.detach().numpy()).max() < 2e-6          # colour ops: <= 1e-6-scale
+    assert rel_err(t2n(xc.grad), xt.grad.numpy()) < 1e-5
+    # zero pattern (translation fill + cutout box) must be identical
+    assert np.array_equal(t2n(y) == 0, yr.detach().numpy() == 0)
+
+
+def test_diffaugment_identity_and_bad_policy():
+    from biggan_tensorflow_amd.DiffAugment import DiffAugment
+    x = cu(np.zeros((1, 8, 8, 3)))
+    assert DiffAugment(x, "") is x
+    with pytest.raises(KeyError):
+        DiffAugment(x, "bogus")
+
+
+# ------------------------------------------------------------------------------------------
+# losses, regulariser, optimiser
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scale", [1.0, -0.02, 3.0])
+def test_hinge_losses_with_flood(scale):
+    Fn = _fn()
+    rng = np.random.default_rng(13)
+    real, fake = rng.standard_normal((16, 1)) * scale, rng.standard_normal((16, 1)) * scale + 0.01
+    rt, ft = torch.tensor(real, requires_grad=True), torch.tensor(fake, requires_grad=True)
+    Ld = R.discriminator_loss("hinge", rt, ft, 0.1)
+    Ld.backward()
+    rc, fc = cu(real, True), cu(fake, True)
+    L = Fn.HingeDLossFn.apply(rc, fc, 0.1, None, 1)
+    L.backward()
+    assert abs(L.item() - Ld.item()) < 1e-6
+    assert rel_err(t2n(rc.grad), rt.grad.numpy()) < 1e-6
+    assert rel_err(t2n(fc.grad), ft.grad.numpy()) < 1e-6
+    ft2 = torch.tensor(fake, requires_grad=True)
+    Lg = R.generator_loss("hinge", ft2, None, 0.05)
+    Lg.backward()
+    fc2 = cu(fake, True)
+    L2 = Fn.HingeGLossFn.apply(fc2, 0.05, None, 1)
+    L2.backward()
+    assert abs(L2.item() - Lg.item()) < 1e-6
+    assert rel_err(t2n(fc2.grad), ft2.grad.numpy()) < 1e-6     # includes the flood sign flip
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 8, 16), (96, 184), (4, 4, 32, 8), (3, 3, 8, 3), (32, 320)])
+def test_ortho_cosine_regulariser(shape):
+    Fn = _fn()
+    rng = np.random.default_rng(sum(shape))
+    w = rng.standard_normal(shape) * 0.05
+    wt = torch.tensor(w, requires_grad=True)
+    Lr = R.ortho_reg_loss(wt, 1e-4, "ortho_cosine")
+    Lr.backward()
+    wc = cu(w, True)
+    L = Fn.OrthoCosineRegFn.apply(wc, 1e-4)
+    L.backward()
+    assert abs(L.item() - Lr.item()) < 2e-5 * abs(Lr.item())
+    assert rel_err(t2n(wc.grad), wt.grad.numpy()) < 1e-4
+
+
+def test_adam_tf_ema_step():
+    hip = _hip()
+    rng = np.random.default_rng(17)
+    n = 10007
+    p, g = rng.standard_normal(n), rng.standard_normal(n)
+    m, v, ema = rng.standard_normal(n) * 0.1, rng.uniform(0, 1, n), rng.standard_normal(n)
+    pc, gc, mc, vc, ec = cu(p), cu(g), cu(m), cu(v), cu(ema)
+    lr_t = 2e-4 * np.sqrt(1 - 0.9 ** 3)
+    hip.check(hip.lib().bg_adam_tf_ema_step(hip.f32(pc), hip.f32(gc), hip.f32(mc), hip.f32(vc), hip.f32(ec),
+                                            lr_t, 0.0, 0.9, 1e-8, 0.999, 1.0, n, hip.stream()))
+    m2 = 0.0 * m + 1.0 * g
+    v2 = 0.9 * v + 0.1 * g * g
+    p2 = p - lr_t * m2 / (np.sqrt(v2) + 1e-8)
+    assert rel_err(t2n(pc), p2) < 1e-6
+    assert rel_err(t2n(mc), m2) < 1e-7
+    assert rel_err(t2n(vc), v2) < 1e-6
+    assert rel_err(t2n(ec), 0.999 * ema + 0.001 * p2) < 1e-6
