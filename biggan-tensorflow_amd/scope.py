@@ -193,7 +193,7 @@ class VariableStore:
                 v.bg_grad.zero_()
 
     # ---- import / export (checkpoint & parity interchange keyed by TF variable names) ---------
-    def load_arrays(self, arrays, strict=True):
+    def load_arrays(self, arrays, strict=True, reset_ema=True):
         with torch.no_grad():
             for k, a in arrays.items():
                 if k not in self.vars:
@@ -201,9 +201,10 @@ class VariableStore:
                         raise KeyError(k)
                     continue
                 self.vars[k].copy_(torch.as_tensor(np.asarray(a), dtype=torch.float32).to(self.device))
-        for arena in self.arenas.values():
-            if arena.ema is not None:
-                arena.ema.copy_(arena.params)
+        if reset_ema:
+            for arena in self.arenas.values():
+                if arena.ema is not None:
+                    arena.ema.copy_(arena.params)
 
     def export_arrays(self):
         return OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in self.vars.items())

@@ -25,52 +25,111 @@ def _loss_close(a, b):
     return abs(a - b) / max(abs(b), 1e-6) <= LOSS_TOL
 
 
+def _scale_ref(name, grads):
+    """The key-side bias of the attention logits (f_conv/bias) has an exactly-zero gradient in exact
+    arithmetic (softmax is invariant to a per-query constant); its fp32 value is cancellation noise of
+    the same layer's kernel gradient, so that norm is the error scale."""
+    if name.endswith("self_attention/f_conv/bias"):
+        return float(np.linalg.norm(grads[name.replace("/bias", "/kernel")].numpy()))
+    return 0.0
+
+
+def _noise_driven(name):
+    """Adam with beta1 = 0 turns ANY non-zero gradient into a +-lr-sized update, so the post-step value
+    of a parameter whose exact gradient is zero is rounding noise on every platform (TensorFlow too)."""
+    return name.endswith("self_attention/f_conv/bias")
+
+
+def _grad_err(a, b, extra_scale=0.0):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-7 * np.sqrt(b.size) + 1e-2 * extra_scale))
+
+
+def _tol(name):
+    # the scalar attention gate: its gradient <dy, o> is a badly conditioned dot product (|grad| is
+    # ~1e-3 of |dy||o|), so fp32 rounding of dy is amplified; every other tensor uses GRAD_TOL
+    return 5e-2 if name.endswith("self_attention/gamma") else GRAD_TOL
+
+
+def _check_grads(tag, gan, ref_grads):
+    for k, g in ref_grads.items():
+        e = _grad_err(t2n(gan.store.vars[k].bg_grad), g.numpy(), _scale_ref(k, ref_grads))
+        assert e < _tol(k), (tag, k, e)
+
+
 def _run_parity(tr, gan, batch, check_state=True):
+    """(1) first-step gradients of both train ops from IDENTICAL state (no update applied);
+    (2) one full iteration (D update, then G update) and the state it leaves behind."""
     cfg = tr.cfg
-    before = tr.vs.export()
-    # ---------------- D step ----------------
-    ro = tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"])
-    ho = gan.d_step(cu(batch["real"]), cu(batch["z_d"]), dev_draws(batch["aug_real"]), dev_draws(batch["aug_fake_d"]))
+    B = batch["real"].shape[0]
+    real, z_d, z_g = cu(batch["real"]), cu(batch["z_d"]), cu(batch["z_g"])
+    a_r, a_fd, a_fg = dev_draws(batch["aug_real"]), dev_draws(batch["aug_fake_d"]), dev_draws(batch["aug_fake_g"])
+    state0 = tr.vs.export()
+    hip0 = gan.store.export_arrays()
+
+    # ---------------- gradient parity, D op ----------------
+    ro = tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], apply=False)
+    ho = gan.d_step(real, z_d, a_r, a_fd, apply=False)
     assert _loss_close(ho["d_loss"].item(), ro["d_loss"].item()), (ho["d_loss"].item(), ro["d_loss"].item())
     assert rel_err(t2n(ho["real_logits"]), ro["real_logits"].detach().numpy()) < GRAD_TOL
     assert rel_err(t2n(ho["fake_logits"]), ro["fake_logits"].detach().numpy()) < GRAD_TOL
     assert rel_err(t2n(ho["fake"]), ro["fake"].detach().numpy()) < GRAD_TOL
-    worst = ("", 0.0)
-    for k, g in ro["grads"].items():
-        hg = t2n(gan.store.vars[k].bg_grad)
-        e = rel_err(hg, g.numpy())
-        if e > worst[1]:
-            worst = (k, e)
-        assert e < GRAD_TOL, ("d grad", k, e)
-    after = tr.vs.export()
-    if check_state:
-        for k in after:
-            if np.array_equal(before[k], after[k]):
-                assert np.array_equal(t2n(gan.store.vars[k]), before[k].astype(np.float32)), ("unchanged", k)
-            else:
-                e = rel_err(t2n(gan.store.vars[k]), after[k])
-                assert e < STATE_TOL, ("d-step state", k, e)
-    # ---------------- G step ----------------
-    B = batch["real"].shape[0]
-    ro = tr.g_step(batch["z_g"], batch["aug_fake_g"])
-    ho = gan.g_step(B, cu(batch["z_g"]), dev_draws(batch["aug_fake_g"]))
+    _check_grads("d grad", gan, ro["grads"])
+    tr.vs.state_updates.clear()
+    gan.store.load_arrays(hip0, reset_ema=False)                  # undo the in-place u / BN-stat updates
+
+    # ---------------- gradient parity, G op ----------------
+    ro = tr.g_step(batch["z_g"], batch["aug_fake_g"], apply=False)
+    ho = gan.g_step(B, z_g, a_fg, apply=False)
     assert _loss_close(ho["g_adv"].item(), ro["g_adv"].item()), (ho["g_adv"].item(), ro["g_adv"].item())
     assert _loss_close(ho["g_loss"].item(), ro["g_loss"].item()), (ho["g_loss"].item(), ro["g_loss"].item())
     if cfg.g_regularization != "none":
         assert _loss_close(ho["g_reg"].item(), ro["g_reg"].item())
     assert rel_err(t2n(ho["fake_logits"]), ro["fake_logits"].detach().numpy()) < GRAD_TOL
-    for k, g in ro["grads"].items():
-        hg = t2n(gan.store.vars[k].bg_grad)
-        e = rel_err(hg, g.numpy())
-        assert e < GRAD_TOL, ("g grad", k, e)
+    _check_grads("g grad", gan, ro["grads"])
+    tr.vs.state_updates.clear()
+    gan.store.load_arrays(hip0, reset_ema=False)
+    if not check_state:
+        return
+
+    # ---------------- one full iteration: D update then G update ----------------
+    tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"])
+    gan.d_step(real, z_d, a_r, a_fd)
+    after = tr.vs.export()
+    hip1 = gan.store.export_arrays()
+    for k in after:
+        if _noise_driven(k):
+            continue
+        if k.endswith("/u") and after[k].size == 1:
+            pass
+        elif np.array_equal(state0[k], after[k]):
+            assert np.array_equal(hip1[k], hip0[k]), ("must not change in the D step", k)
+        else:
+            assert not np.array_equal(hip1[k], hip0[k]), ("must change in the D step", k)
+            e = rel_err(hip1[k], after[k])
+            assert e < STATE_TOL, ("d-step state", k, e)
+    ro = tr.g_step(batch["z_g"], batch["aug_fake_g"])
+    ho = gan.g_step(B, z_g, a_fg)
+    assert abs(ho["g_loss"].item() - ro["g_loss"].item()) <= 1e-3 * max(abs(ro["g_loss"].item()), 1e-6)
     after2 = tr.vs.export()
-    if check_state:
-        for k in after2:
-            e = rel_err(t2n(gan.store.vars[k]), after2[k]) if np.linalg.norm(after2[k]) > 0 else 0.0
-            assert e < STATE_TOL, ("g-step state", k, e)
-        for k, s in tr.ema.items():
-            e = rel_err(t2n(gan.g_arena.view(gan.g_arena.ema, k)), s.numpy())
-            assert e < STATE_TOL, ("ema", k, e)
+    hip2 = gan.store.export_arrays()
+    for k in after2:
+        if _noise_driven(k):
+            continue
+        if k.endswith("/u") and after2[k].size == 1:
+            pass                         # a 1-element u is +-1 up to an ulp after its first update
+        elif np.array_equal(after[k], after2[k]):
+            assert np.array_equal(hip2[k], hip1[k]), ("must not change in the G step", k)
+        else:
+            assert not np.array_equal(hip2[k], hip1[k]), ("must change in the G step", k)
+        e = rel_err(hip2[k], after2[k]) if np.linalg.norm(after2[k]) > 0 else 0.0
+        assert e < STATE_TOL, ("g-step state", k, e)
+    for k, s_ in tr.ema.items():
+        if _noise_driven(k):
+            continue
+        e = rel_err(t2n(gan.g_arena.view(gan.g_arena.ema, k)), s_.numpy())
+        assert e < STATE_TOL, ("ema", k, e)
 
 
 @pytest.mark.parametrize("img,ch,zd,B", [(64, 8, 64, 4), (128, 8, 256, 2)])
@@ -108,7 +167,7 @@ def test_two_consecutive_iterations():
 
 def test_plumbing_config_img64_ch32_batch16():
     """BASELINE config 1 (plumbing): smallest reference-supported size, ch=32, batch=16, fp32."""
-    tr = oracle_trainer(64, 32, 256, 16, dtype=torch.float32)
+    tr = oracle_trainer(64, 32, 256, 16)
     gan = hip_model_like(tr)
     batch = RM.synthetic_batch(tr.cfg, 9, 16)
     _run_parity(tr, gan, batch, check_state=False)
