@@ -86,31 +86,42 @@ def step_flops_per_image(img, ch):
     return 2.0 * (4 * macs_g + 8 * macs_d), 2.0 * macs_g, 2.0 * macs_d
 
 
-def cpu_baseline(img, ch, sample_batch, steps):
+def host_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(img, ch, sample_batch, steps, note=lambda m: None):
     """Oracle (torch-CPU fp32 restatement) timed on this host's cores: images/sec."""
     import torch
     from oracle import ref_model as RM
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     cfg = RM.Config(img_size=img, ch=ch, batch_size=sample_batch)
     tr = RM.Trainer(cfg, torch.float32).build()
+    note("cpu baseline: oracle built, %d threads" % cores)
     batch = RM.synthetic_batch(cfg, 1, sample_batch)
-
-    def one():
-        tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"])
-        tr.g_step(batch["z_g"], batch["aug_fake_g"])
-    one()                                   # warm-up
     t0 = time.time()
-    for _ in range(steps):
-        one()
+    for i in range(steps):
+        tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"])
+        note("cpu baseline: D step %d done (%.1fs)" % (i, time.time() - t0))
+        tr.g_step(batch["z_g"], batch["aug_fake_g"])
+        note("cpu baseline: G step %d done (%.1fs)" % (i, time.time() - t0))
     dt = time.time() - t0
-    return {"value": sample_batch * steps / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d step(s) of the same D+G iteration at batch %d (torch-CPU fp32 oracle; TensorFlow, the "
-                      "reference's substrate, is not installed)" % (steps, sample_batch)}
+    return {"value": round(sample_batch * steps / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d D+G iteration(s) of the same workload at batch %d, %.1f s (torch-CPU fp32 oracle; "
+                      "TensorFlow, the reference's substrate, is not installed)" % (steps, sample_batch, dt)}
 
 
 def main():
@@ -126,6 +137,7 @@ def main():
     ap.add_argument("--no_roofline", action="store_true")
     a = ap.parse_args()
 
+    t_start = time.perf_counter()
     import torch
     import biggan_tensorflow_amd  # noqa: F401
     from biggan_tensorflow_amd import hip, main as M, model, parallel, scope as S
@@ -152,8 +164,15 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    def note(msg):
+        if rank == 0:
+            print("[bench %7.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    note("model built: %s" % desc)
+    for i in range(a.warmup):
         gan.train_step(real)
+        torch.cuda.synchronize()
+        note("warmup step %d done" % i)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -166,6 +185,7 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
     value = B * world * a.steps / dt
+    note("timed %d steps: %.1f ms/step, %.1f images/sec" % (a.steps, ms_per_step, value))
 
     roof = None
     if not a.no_roofline:
@@ -179,6 +199,7 @@ def main():
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         L.bg_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
         L.bg_prof_enable(0)
+        note("roofline pass done")
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         fpi, fg, fd = step_flops_per_image(img, ch)
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -191,8 +212,10 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        sb = 4 if img >= 128 else 8
-        cpu = cpu_baseline(img, ch, sb, 2)
+        sb = 2 if img >= 128 else 8
+        note("cpu baseline (oracle, batch %d) ..." % sb)
+        cpu = cpu_baseline(img, ch, sb, 1, note)
+        note("cpu baseline done")
 
     if rank == 0:
         out = {

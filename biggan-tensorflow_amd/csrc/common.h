@@ -55,7 +55,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh /* >= 4 floats
 
 // profiling hooks (prof.cpp)
 struct ProfScope {
-    ProfScope(hipStream_t s, double flops);
+    ProfScope(hipStream_t s, double flops, const char* tag = nullptr);
     ~ProfScope();
     hipStream_t stream;
     int slot;

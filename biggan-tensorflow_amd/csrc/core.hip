@@ -21,13 +21,14 @@ void set_error(const char* fmt, ...) {
 struct ProfRec {
     hipEvent_t e0, e1;
     double flops;
+    char tag[112];
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof_recs;     // completed-but-uncollected launches
 static std::vector<ProfRec> g_prof_pool;     // reusable event pairs
 
-ProfScope::ProfScope(hipStream_t s, double flops) : stream(s), slot(-1) {
+ProfScope::ProfScope(hipStream_t s, double flops, const char* tag) : stream(s), slot(-1) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
@@ -38,6 +39,8 @@ ProfScope::ProfScope(hipStream_t s, double flops) : stream(s), slot(-1) {
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     }
     r.flops = flops;
+    strncpy(r.tag, tag ? tag : "", sizeof(r.tag) - 1);
+    r.tag[sizeof(r.tag) - 1] = 0;
     (void)hipEventRecord(r.e0, s);
     g_prof_recs.push_back(r);
     slot = (int)g_prof_recs.size() - 1;
@@ -66,6 +69,24 @@ void bg_prof_reset(void) {
     std::lock_guard<std::mutex> lk(bg::g_prof_mu);
     for (auto& r : bg::g_prof_recs) bg::g_prof_pool.push_back(r);
     bg::g_prof_recs.clear();
+}
+
+int bg_prof_dump(const char* path) {
+    std::lock_guard<std::mutex> lk(bg::g_prof_mu);
+    FILE* f = fopen(path, "w");
+    if (!f) {
+        bg::set_error("bg_prof_dump: cannot open %s", path);
+        return BG_ERR_ARG;
+    }
+    fprintf(f, "tag,flops,ms\n");
+    for (auto& r : bg::g_prof_recs) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) continue;
+        fprintf(f, "%s,%.0f,%.6f\n", r.tag, r.flops, (double)t);
+    }
+    fclose(f);
+    return BG_OK;
 }
 
 int bg_prof_collect(double* total_ms, double* total_flops, int64_t* launches) {

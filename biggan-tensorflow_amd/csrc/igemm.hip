@@ -678,6 +678,17 @@ static int check_deconv(const BgConvDesc* d) {
     return BG_OK;
 }
 
+struct Tag {
+    char s[112];
+    Tag(const char* op, const BgConvDesc* d) {
+        snprintf(s, sizeof(s), "%s N%d H%d Cin%d Cout%d Ho%d k%d s%d", op, d->N, d->H, d->Cin, d->Cout, d->Ho, d->k,
+                 d->stride);
+    }
+    Tag(const char* op, const BgGemmDesc* d) {
+        snprintf(s, sizeof(s), "%s M%d N%d K%d tA%d tB%d b%d", op, d->M, d->N, d->K, d->transA, d->transB, d->batch);
+    }
+};
+
 static double conv_flops(const BgConvDesc* d, bool deconv) {
     const double px = deconv ? (double)d->N * d->H * d->W : (double)d->N * d->Ho * d->Wo;
     return 2.0 * px * d->k * d->k * d->Cin * d->Cout;
@@ -705,7 +716,8 @@ int bg_conv2d_fwd(const BgConvDesc* d, const float* x, const float* w, const flo
     p.out_ld = d->Cout; p.accumulate = accumulate; p.batch = 1;
     p.a_vec = (d->Cin % 4 == 0) && aligned16(x);
     p.b_vec = (d->Cout % 4 == 0) && aligned16(w);
-    ProfScope prof(as_stream(stream), conv_flops(d, false));
+    Tag tag("conv2d_fwd", d);
+    ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
     return launch_nn(p, false, false, 1, as_stream(stream));
 }
 
@@ -727,7 +739,8 @@ int bg_conv2d_dgrad(const BgConvDesc* d, const float* dy, const float* w, const 
     p.out_ld = d->Cin; p.accumulate = accumulate; p.batch = 1;
     p.a_vec = (d->Cout % 4 == 0) && aligned16(dy);
     p.b_vec = (d->Cout % 4 == 0) && aligned16(w);
-    ProfScope prof(as_stream(stream), conv_flops(d, false));
+    Tag tag("conv2d_dgrad", d);
+    ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
     return launch_nn(p, true, g.reflect != 0, d->stride * d->stride, as_stream(stream));
 }
 
@@ -751,7 +764,8 @@ int bg_conv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, float*
     p.out_ld = d->Cout; p.out_tap_stride = (int64_t)d->Cin * d->Cout; p.batch = 1;
     p.a_vec = (d->Cin % 4 == 0) && aligned16(x);
     p.b_vec = (d->Cout % 4 == 0) && aligned16(dy);
-    ProfScope prof(as_stream(stream), conv_flops(d, false));
+    Tag tag("conv2d_wgrad", d);
+    ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
     return launch_tn(p, d->k * d->k, dw, ws, ws_bytes, as_stream(stream));
 }
 
@@ -772,7 +786,8 @@ int bg_deconv2d_fwd(const BgConvDesc* d, const float* x, const float* w, const f
     p.out_ld = d->Cout; p.accumulate = accumulate; p.batch = 1;
     p.a_vec = (d->Cin % 4 == 0) && aligned16(x);
     p.b_vec = (d->Cin % 4 == 0) && aligned16(w);
-    ProfScope prof(as_stream(stream), conv_flops(d, true));
+    Tag tag("deconv2d_fwd", d);
+    ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
     return launch_nn(p, true, false, d->stride * d->stride, as_stream(stream));
 }
 
@@ -792,7 +807,8 @@ int bg_deconv2d_dgrad(const BgConvDesc* d, const float* dy, const float* w, cons
     p.out_ld = d->Cin; p.accumulate = accumulate; p.batch = 1;
     p.a_vec = (d->Cout % 4 == 0) && aligned16(dy);
     p.b_vec = (d->Cin % 4 == 0) && aligned16(w);
-    ProfScope prof(as_stream(stream), conv_flops(d, true));
+    Tag tag("deconv2d_dgrad", d);
+    ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
     return launch_nn(p, false, false, 1, as_stream(stream));
 }
 
@@ -817,7 +833,8 @@ int bg_deconv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, floa
     p.out_ld = d->Cin; p.out_tap_stride = (int64_t)d->Cin * d->Cout; p.batch = 1;
     p.a_vec = (d->Cout % 4 == 0) && aligned16(dy);
     p.b_vec = (d->Cin % 4 == 0) && aligned16(x);
-    ProfScope prof(as_stream(stream), conv_flops(d, true));
+    Tag tag("deconv2d_wgrad", d);
+    ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
     return launch_tn(p, d->k * d->k, dw, ws, ws_bytes, as_stream(stream));
 }
 
@@ -847,7 +864,8 @@ int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bi
             p.b_vec = (d->K % 4 == 0) && (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
         else
             p.b_vec = (d->N % 4 == 0) && (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
-        ProfScope prof(as_stream(stream), flops);
+        Tag tag("gemm", d);
+        ProfScope prof(as_stream(stream), flops, tag.s);
         return launch_nn(p, d->transB != 0, false, d->batch, as_stream(stream));
     }
     BG_REQUIRE(!d->transB, "bg_gemm: transA && transB unsupported");
@@ -865,7 +883,8 @@ int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bi
     p.b_vec = (d->N % 4 == 0) && (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
     // out_tap_stride must describe a contiguous [Ca][Cb] tile for the split-K path
     p.out_tap_stride = (int64_t)d->M * d->N;
-    ProfScope prof(as_stream(stream), flops);
+    Tag tag("gemm", d);
+    ProfScope prof(as_stream(stream), flops, tag.s);
     return launch_tn(p, 1, C, ws, ws_bytes, as_stream(stream));
 }
 

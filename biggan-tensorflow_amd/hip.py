@@ -83,6 +83,7 @@ SIGNATURES = {
     "bg_prof_enable": (None, [c_int]),
     "bg_prof_reset": (None, []),
     "bg_prof_collect": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+    "bg_prof_dump": (c_int, [c_char_p]),
 }
 
 

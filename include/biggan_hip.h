@@ -213,6 +213,8 @@ int bg_adam_tf_ema_step(float* p, const float* g, float* m, float* v, float* ema
 void bg_prof_enable(int on);
 void bg_prof_reset(void);
 int  bg_prof_collect(double* total_ms, double* total_flops, int64_t* launches);
+/* write one CSV line (tag,flops,ms) per recorded launch; does not clear the records */
+int  bg_prof_dump(const char* path);
 
 #ifdef __cplusplus
 }

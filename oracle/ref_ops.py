@@ -180,7 +180,12 @@ def _maybe_regularize(vs, opt, scope, w, kind):
         return
     if any(n == scope for n, _ in vs.reg_losses):
         return                       # reuse=True instantiation: variable (and its loss) already exist
-    vs.reg_losses.append((scope, ortho_reg_loss(w, reg["scale"], reg["type"])))
+    if reg["type"] == "ortho_cosine" and w.shape[-1] > 256:
+        # literal form is O(c^3) (8.8 TFLOP for first/dense2 at ch=64); the closed form is the same
+        # function (tests/test_oracle.py::test_ortho_cosine_closed_form)
+        vs.reg_losses.append((scope, ortho_cosine_closed_form(w, reg["scale"])))
+    else:
+        vs.reg_losses.append((scope, ortho_reg_loss(w, reg["scale"], reg["type"])))
 
 
 # ----------------------------------------------------------------------------------

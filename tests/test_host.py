@@ -1,0 +1,181 @@
+"""CPU tests of the host logic: flag surface, scope/variable semantics, parameter manifest parity
+with the oracle, C-ABI symbol coverage (no compute calls - there is no GPU here)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import biggan_tensorflow_amd  # noqa: F401
+from biggan_tensorflow_amd import hip, main as M, model, scope as S, utils
+from biggan_tensorflow_amd import DiffAugment as DA
+from oracle import ref_model as RM
+from oracle import ref_ops as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+# ---------------------------------------------------------------- flag surface (main.py:9-147)
+def test_flag_surface_matches_golden_listing():
+    """tests/golden/flags.json lists the reference's 119 flags (name, type, default); it is data
+    extracted once by tests/golden/make_flags.py, not reference source."""
+    ref = json.load(open(os.path.join(GOLDEN, "flags.json")))
+    assert len(ref) == 119
+    mine = {n: (t.__name__, d) for n, t, d in M.FLAGS}
+    assert len(mine) == 119
+    for name, typ, default in ref:
+        assert name in mine, name
+        assert mine[name][0] == typ, (name, typ, mine[name][0])
+        assert mine[name][1] == default, (name, default, mine[name][1])
+
+
+def test_defaults_and_str2bool_leniency():
+    a = M.parse_args([], make_dirs=False)
+    assert a.gan_type == "ra-dragan" and a.img_size == 256 and a.ch == 64 and a.batch_size == 16
+    assert a.sn is True and a.g_regularization == "ortho_cosine" and a.da_policy == "full"
+    # utils.py:173-174 is a substring test
+    assert utils.str2bool("") and utils.str2bool("t") and utils.str2bool("rue") and utils.str2bool("TRUE")
+    assert not utils.str2bool("false") and not utils.str2bool("yes")
+    assert M.parse_args(["--sn", "false"], make_dirs=False).sn is False
+
+
+def test_check_args_creates_folders(tmp_path):
+    d = [str(tmp_path / n) for n in ("c", "r", "l", "s")]
+    M.parse_args(["--checkpoint_dir", d[0], "--result_dir", d[1], "--log_dir", d[2], "--sample_dir", d[3]])
+    assert all(os.path.isdir(x) for x in d)
+
+
+def test_out_of_scope_flags_rejected_at_build():
+    for extra in (["--deep", "true"], ["--n_labels", "10"], ["--gan_type", "ra-dragan"], ["--g_final_layer", "true"],
+                  ["--bn_type", "batch_renorm"], ["--virtual_batches", "2"]):
+        argv = ["--gan_type", "hinge", "--img_size", "64"] + extra
+        with pytest.raises(NotImplementedError):
+            model.BigGAN(M.parse_args(argv, make_dirs=False), device="cpu", store=S.VariableStore("cpu"))
+    with pytest.raises(ValueError):
+        g = model.BigGAN(M.parse_args(["--gan_type", "hinge", "--img_size", "96"], make_dirs=False), device="cpu",
+                         store=S.VariableStore("cpu"))
+        g.generator(torch.empty(2, 1, 1, 256, device="meta"))
+
+
+# ---------------------------------------------------------------- scope semantics
+def test_variable_scope_names_and_default_name_uniquifying():
+    st = S.VariableStore("cpu")
+    with st.variable_scope("discriminator"):
+        with st.variable_scope("res1"):
+            with st.variable_scope(None, default_name="prelu") as a:
+                pass
+            with st.variable_scope(None, default_name="prelu") as b:
+                pass
+        with st.variable_scope("res1"):                       # re-entered: counters were cleared
+            with st.variable_scope(None, default_name="prelu") as c:
+                pass
+    assert a == "discriminator/res1/prelu" and b == "discriminator/res1/prelu_1" and c == a
+    with st.variable_scope("g"):
+        v = st.get_variable("kernel", [3, 4])
+        assert st.get_variable("kernel", [3, 4]) is v
+        with pytest.raises(ValueError):
+            st.get_variable("kernel", [4, 4])
+    assert v.bg_name == "g/kernel" and v.requires_grad
+
+
+def test_initialisers():
+    rng = np.random.default_rng(0)
+    a = S.truncated_normal_initializer(0.0, 0.02)((1000, 50), rng)
+    assert np.abs(a).max() <= 0.04 + 1e-9 and abs(a.std() - 0.02 * 0.88) < 2e-3
+    assert S.constant_initializer(1.0)((3,), rng).tolist() == [1, 1, 1]
+
+
+# ---------------------------------------------------------------- manifest == oracle manifest
+@pytest.mark.parametrize("size", [64, 128, 256, 512])
+def test_manifest_matches_oracle(size):
+    args = M.parse_args(["--gan_type", "hinge", "--img_size", str(size), "--ch", "8"], make_dirs=False)
+    store = S.VariableStore("cpu")
+    gan = model.BigGAN(args, device="cpu", store=store)
+    img = gan.generator(torch.empty(2, 1, 1, gan.z_dim, device="meta"))
+    out = gan.discriminator(img)
+    assert tuple(img.shape) == (2, size, size, 3) and tuple(out["real"].shape) == (2, 1)
+    tr = RM.Trainer(RM.Config(img_size=size, ch=8, batch_size=2), torch.float32).build()
+    mine = {k: tuple(v.shape) for k, v in store.vars.items()}
+    ref = {k: tuple(v.shape) for k, v in tr.vs.vars.items()}
+    assert mine == ref
+    assert {k for k in mine if store.trainable[k]} == {k for k in ref if tr.vs.trainable[k]}
+    # second instantiation resolves the same names (eager re-execution == reuse)
+    n = len(store.vars)
+    gan.generator(torch.empty(2, 1, 1, gan.z_dim, device="meta"))
+    gan.discriminator(img)
+    assert len(store.vars) == n
+
+
+def test_arena_packing_on_cpu():
+    args = M.parse_args(["--gan_type", "hinge", "--img_size", "64", "--ch", "8", "--z_dim", "64"], make_dirs=False)
+    store = S.VariableStore("cpu")
+    gan = model.BigGAN(args, device="cpu", store=store)
+    gan.discriminator(gan.generator(torch.empty(2, 1, 1, 64, device="meta")))
+    before = store.export_arrays()
+    store.pack()
+    after = store.export_arrays()
+    assert all(np.array_equal(before[k], after[k]) for k in before)
+    ga = store.arenas["generator"]
+    assert ga.ema is not None and store.arenas["discriminator"].ema is None
+    assert torch.equal(ga.ema, ga.params)
+    for name in ga.names:
+        off, n, shape = ga.offsets[name]
+        assert off % 64 == 0
+        v = store.vars[name]
+        assert v.data_ptr() == ga.params.data_ptr() + 4 * off and tuple(v.shape) == shape
+        assert v.bg_grad.data_ptr() == ga.grads.data_ptr() + 4 * off
+    with pytest.raises(ValueError):
+        store.get_variable("new_variable", [1])
+
+
+# ---------------------------------------------------------------- DiffAugment host logic
+def test_diffaugment_policy_and_constants():
+    assert DA.augment_params(128) == R.diffaugment_params(128) == (16, 64, 129)
+    assert DA.policy_bits("color,translation,cutout") == 7 and DA.policy_bits("translation") == 2
+    with pytest.raises(KeyError):
+        DA.policy_bits("flip")
+    with pytest.raises(NotImplementedError):
+        DA.policy_bits("cutout,color")
+    x = torch.zeros(1, 8, 8, 3)
+    assert DA.DiffAugment(x, "") is x
+    d = DA.draw(64, 128, "cpu", torch.Generator().manual_seed(0))
+    assert d["t_x"].dtype == torch.int32 and int(d["t_x"].abs().max()) <= 16
+    assert int(d["o_x"].min()) >= 0 and int(d["o_x"].max()) <= 128
+
+
+# ---------------------------------------------------------------- C ABI
+def _header_symbols():
+    h = open(os.path.join(ROOT, "include", "biggan_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(bg_[a-z0-9_]+)\s*\(", h)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = _header_symbols()
+    assert len(syms) >= 45
+    assert sorted(hip.SIGNATURES.keys()) == syms              # the binding covers the whole header
+    L = hip.lib()                                             # dlopen + getattr of every symbol
+    assert L.bg_abi_version() == 1 and L.bg_target_arch() == b"gfx950"
+    assert L.bg_last_error() is not None
+    # workspace queries are pure host functions
+    d = hip.conv_desc(64, 128, 128, 64, 128, 128, 64, 3, 1, 1, hip.PAD_REFLECT)
+    assert L.bg_conv2d_wgrad_workspace_bytes(d) % 4 == 0
+    assert L.bg_spectral_norm_workspace_bytes(10, 20) == 4 * 34
+
+
+def test_ops_fail_loudly_without_gpu():
+    from biggan_tensorflow_amd import functional as Fn
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Fn.PReluFn.apply(torch.zeros(2, 4), torch.zeros(4))
+    with pytest.raises(RuntimeError):
+        Fn.Conv2dFn.apply(torch.zeros(1, 4, 4, 4), torch.zeros(3, 3, 4, 4), None, 1, 1, 4, 4, hip.PAD_REFLECT)
+
+
+def test_bench_flop_model_matches_baseline_md():
+    import bench
+    for (img, ch), gf in {(128, 64): 96.24, (128, 96): 212.16, (256, 96): 713.44, (512, 128): 2376.77,
+                          (64, 32): 4.74}.items():
+        assert round(bench.step_flops_per_image(img, ch)[0] / 1e9, 2) == gf
