@@ -7,9 +7,10 @@
 // Tiling: 256 threads = 4 waves (64 lanes).  Each wave owns TM x TN MFMA tiles of 32x32; the block
 // tile is (32*TM*WM) x (32*TN*WN); K advances in steps of 16 floats through double-buffered LDS,
 // with the next tile's global loads in flight (held in registers) while the current one is on the
-// matrix pipe.  A tiles are stored K-major in LDS ([k][m], row stride == 2 mod 8) so that both
-// the transposing ds_write_b32 (4 per float4) and the MFMA operand ds_read_b32 (lane = row) are
-// bank-conflict free.
+// matrix pipe, and the MFMA operand reads of k-step kk+1 issued before the MFMAs of k-step kk.
+// A tiles are stored K-major in LDS ([k][m], row stride == 2 mod 8) so that both the transposing
+// ds_write_b32 (4 per float4) and the operand ds_read_b32 (lane = row) are bank-conflict free.
+// Blocks are renumbered so that the tiles sharing operand panels run on one XCD (shared L2).
 #include "common.h"
 #include "igemm.h"
 
@@ -27,10 +28,11 @@ struct RowPos {
     bool valid;
 };
 
+template <int MODE>
 __device__ __forceinline__ RowPos decompose_row(const Gather& g, int m, int M, int ph, int pw) {
     RowPos r;
     r.valid = m < M;
-    if (g.plain) {
+    if (MODE == GATHER_PLAIN) {
         r.b = m;
         r.ho = 0;
         r.wo = 0;
@@ -59,8 +61,8 @@ __device__ __forceinline__ int conv_src(int o, int kk, int stride, int pad, int 
 // one axis of a TCONV-mode gather: numerator hn = o + pad - kk must be a non-negative multiple of stride
 __device__ __forceinline__ int tconv_src_from_num(int hn, int stride, int n) {
     if (hn < 0) return -1;
-    int s = hn / stride;
-    if (s * stride != hn) return -1;
+    int s = stride == 1 ? hn : (hn >> 1);
+    if (stride != 1 && (hn & 1)) return -1;
     return s < n ? s : -1;
 }
 
@@ -79,24 +81,24 @@ __device__ __forceinline__ int tconv_mirror_src(int o, int kk, int stride, int p
 }
 
 // up to 4 source offsets (element offsets into the source tensor, -1 = none) for row r and tap (kh,kw)
-template <bool MIRROR>
+template <int MODE, bool MIRROR>
 __device__ __forceinline__ void tap_sources(const Gather& g, const RowPos& r, int kh, int kw,
                                             int64_t (&off)[MIRROR ? 4 : 1]) {
 #pragma unroll
     for (int i = 0; i < (MIRROR ? 4 : 1); ++i) off[i] = -1;
     if (!r.valid) return;
-    if (g.plain) {
+    if (MODE == GATHER_PLAIN) {
         off[0] = (int64_t)r.b * g.ld;
         return;
     }
     int h0, w0, h1 = -1, w1 = -1;
-    if (g.mode == GATHER_CONV) {
+    if (MODE == GATHER_CONV) {
         h0 = conv_src(r.ho, kh, g.stride, g.pad, g.reflect, g.Hs);
         w0 = conv_src(r.wo, kw, g.stride, g.pad, g.reflect, g.Ws);
     } else {
         h0 = tconv_src_from_num(r.ho + g.pad - kh, g.stride, g.Hs);
         w0 = tconv_src_from_num(r.wo + g.pad - kw, g.stride, g.Ws);
-        if (MIRROR && g.reflect) {
+        if (MIRROR) {
             h1 = tconv_mirror_src(r.ho, kh, g.stride, g.pad, g.Ho, g.Hs);
             w1 = tconv_mirror_src(r.wo, kw, g.stride, g.pad, g.Wo, g.Ws);
         }
@@ -112,11 +114,12 @@ __device__ __forceinline__ void tap_sources(const Gather& g, const RowPos& r, in
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-__device__ __forceinline__ float4 load_chan4(const float* base, int64_t off, int c, int C, bool vec) {
+template <bool VEC>
+__device__ __forceinline__ float4 load_chan4(const float* base, int64_t off, int c, int C) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (off < 0) return v;
     const float* p = base + off + c;
-    if (vec) {
+    if (VEC) {
         if (c < C) v = ld4(p);
     } else {
         if (c + 0 < C) v.x = p[0];
@@ -134,10 +137,44 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) {
     a.w += b.w;
 }
 
+// XCD-aware renumbering: hardware deals consecutive block ids round-robin over the 8 XCDs; give each
+// XCD a contiguous range of logical tiles so neighbouring tiles share one L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int x = bid & 7, j = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// TM x TN MFMA tiles of one wave over one 16-deep K tile, operand reads software-pipelined
+template <int TM, int TN, int LDA, int LDB>
+__device__ __forceinline__ void mma_tile(const float* __restrict__ as, const float* __restrict__ bs, int a_rd, int b_rd,
+                                         floatx16 (&acc)[TM][TN]) {
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = as[a_rd + 32 * i];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = bs[b_rd + 32 * j];
+#pragma unroll
+    for (int kk = 0; kk < BKT / 2; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BKT / 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[nxt][i] = as[a_rd + 2 * (kk + 1) * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[nxt][j] = bs[b_rd + 2 * (kk + 1) * LDB + 32 * j];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // NN kernel
 // ------------------------------------------------------------------------------------------
-template <int TM, int TN, int WM, int WN, bool BT, bool MIRROR>
+template <int TM, int TN, int WM, int WN, bool BT, int MODE, bool MIRROR, bool VEC>
 __global__ __launch_bounds__(256) void nn_kernel(const NNParams p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int LDA = BM + 2;                 // == 2 (mod 8): conflict-free transposing writes
@@ -153,60 +190,74 @@ __global__ __launch_bounds__(256) void nn_kernel(const NNParams p) {
     const int wm = wave / WN, wn = wave % WN;
 
     const Gather& g = p.g;
-    const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
+    const int zs = blockIdx.z % p.splitk, zo = blockIdx.z / p.splitk;
     const float* Abase = p.A;
     const float* Bbase = p.B;
     float* Obase = p.out;
     int ph = 0, pw = 0;
-    if (p.batch > 1) {
-        Abase += (int64_t)blockIdx.z * p.strideA;
-        Bbase += (int64_t)blockIdx.z * p.strideB;
-        Obase += (int64_t)blockIdx.z * p.strideC;
-    } else if (g.pstep > 1) {
-        ph = blockIdx.z / g.pstep;
-        pw = blockIdx.z % g.pstep;
+    if (MODE == GATHER_PLAIN) {
+        Abase += (int64_t)zo * p.strideA;
+        Bbase += (int64_t)zo * p.strideB;
+        Obase += (int64_t)zo * p.strideC;
+    } else if (MODE == GATHER_TCONV) {
+        ph = zo / g.pstep;
+        pw = zo % g.pstep;
     }
 
     // tap enumeration of this phase
     int kh0 = 0, kw0 = 0, kstep = 1, nkh = g.k, nkw = g.k;
-    if (g.mode == GATHER_TCONV && g.pstep > 1) {
+    if (MODE == GATHER_TCONV && g.pstep > 1) {
         kstep = g.stride;
         kh0 = (ph + g.pad) % g.stride;
         kw0 = (pw + g.pad) % g.stride;
         nkh = (g.k - kh0 + g.stride - 1) / g.stride;
         nkw = (g.k - kw0 + g.stride - 1) / g.stride;
     }
+    if (MODE == GATHER_PLAIN) {
+        nkh = 1;
+        nkw = 1;
+    }
     const int kc = (p.C + BKT - 1) / BKT;
-    const int niter = nkh * nkw * kc;
+    const int niter_all = nkh * nkw * kc;
+    const int ips = (niter_all + p.splitk - 1) / p.splitk;
+    const int it0 = zs * ips;
+    const int it1 = min(niter_all, it0 + ips);
+    const int niter = max(0, it1 - it0);
 
     // A-load rows of this thread
     const int a_kq = (t & 3) * 4;
     RowPos rows[AROWS];
 #pragma unroll
-    for (int i = 0; i < AROWS; ++i) rows[i] = decompose_row(g, m0 + (t >> 2) + 64 * i, p.M, ph, pw);
+    for (int i = 0; i < AROWS; ++i) rows[i] = decompose_row<MODE>(g, m0 + (t >> 2) + 64 * i, p.M, ph, pw);
     int64_t aoff[AROWS][NSRC];
 
-    // load-stream state
-    int l_ih = 0, l_iw = 0, l_ic = 0;
+    // load-stream state, positioned at iteration it0
+    int l_ic = it0 % kc;
+    int l_iw = (it0 / kc) % nkw;
+    int l_ih = (it0 / kc) / nkw;
+    bool need_off = true;
     float4 ra[AROWS];
     constexpr int BLOADS = BT ? (BN + 63) / 64 : (BKT * BN / 4 + 255) / 256;
     float4 rb[BLOADS];
 
     auto load_tile = [&]() {
         const int kh = kh0 + l_ih * kstep, kw = kw0 + l_iw * kstep;
-        if (l_ic == 0) {
+        if (need_off || l_ic == 0) {
 #pragma unroll
-            for (int i = 0; i < AROWS; ++i) tap_sources<MIRROR>(g, rows[i], kh, kw, aoff[i]);
+            for (int i = 0; i < AROWS; ++i) tap_sources<MODE, MIRROR>(g, rows[i], kh, kw, aoff[i]);
+            need_off = false;
         }
         const int c0 = l_ic * BKT;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
-            float4 v = load_chan4(Abase, aoff[i][0], c0 + a_kq, p.C, p.a_vec);
+            float4 v = load_chan4<VEC>(Abase, aoff[i][0], c0 + a_kq, p.C);
             if (MIRROR) {
 #pragma unroll
-                for (int s = 1; s < NSRC; ++s) add4(v, load_chan4(Abase, aoff[i][s], c0 + a_kq, p.C, p.a_vec));
+                for (int s = 1; s < NSRC; ++s) add4(v, load_chan4<VEC>(Abase, aoff[i][s], c0 + a_kq, p.C));
             }
             ra[i] = v;
         }
@@ -221,7 +272,7 @@ __global__ __launch_bounds__(256) void nn_kernel(const NNParams p) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (nrel < BN && n < p.N) {
                     const float* q = wt + (int64_t)n * p.ldn + c;
-                    if (p.b_vec) {
+                    if (VEC) {
                         if (c < p.C) v = ld4(q);
                     } else {
                         if (c + 0 < p.C) v.x = q[0];
@@ -242,7 +293,7 @@ __global__ __launch_bounds__(256) void nn_kernel(const NNParams p) {
                 const int c = c0 + kk, n = n0 + nq;
                 if (idx < BKT * BN / 4 && c < p.C) {
                     const float* q = wt + (int64_t)c * p.ldk + n;
-                    if (p.b_vec) {
+                    if (VEC) {
                         if (n < p.N) v = ld4(q);
                     } else {
                         if (n + 0 < p.N) v.x = q[0];
@@ -306,8 +357,10 @@ __global__ __launch_bounds__(256) void nn_kernel(const NNParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile();
-    store_tile(0);
+    if (niter > 0) {
+        load_tile();
+        store_tile(0);
+    }
     __syncthreads();
 
     const int a_rd = (lane >> 5) * LDA + wm * 32 * TM + (lane & 31);
@@ -316,27 +369,15 @@ __global__ __launch_bounds__(256) void nn_kernel(const NNParams p) {
     for (int it = 0; it < niter; ++it) {
         const int cur = it & 1;
         if (it + 1 < niter) load_tile();
-        const float* as = As[cur];
-        const float* bs = Bs[cur];
-#pragma unroll
-        for (int kk = 0; kk < BKT / 2; ++kk) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[a_rd + 2 * kk * LDA + 32 * i];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[b_rd + 2 * kk * LDB + 32 * j];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+        mma_tile<TM, TN, LDA, LDB>(As[cur], Bs[cur], a_rd, b_rd, acc);
         if (it + 1 < niter) store_tile(cur ^ 1);
         __syncthreads();
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
-    const float alpha = p.alpha ? *p.alpha : 1.0f;
+    const bool partial = p.splitk > 1;
+    const float alpha = (!partial && p.alpha) ? *p.alpha : 1.0f;
+    if (partial) Obase = p.slabs + (int64_t)zs * p.slab_stride + (Obase - p.out);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -344,10 +385,10 @@ __global__ __launch_bounds__(256) void nn_kernel(const NNParams p) {
             const int row = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row >= p.M) continue;
             int64_t ooff;
-            if (g.plain || g.pstep == 1) {
+            if (MODE != GATHER_TCONV) {
                 ooff = (int64_t)row * p.out_ld;
             } else {
-                RowPos rp = decompose_row(g, row, p.M, ph, pw);
+                RowPos rp = decompose_row<MODE>(g, row, p.M, ph, pw);
                 ooff = (((int64_t)rp.b * g.Ho + rp.ho) * g.Wo + rp.wo) * p.out_ld;
             }
 #pragma unroll
@@ -355,9 +396,11 @@ __global__ __launch_bounds__(256) void nn_kernel(const NNParams p) {
                 const int col = n0 + wn * 32 * TN + 32 * j + (lane & 31);
                 if (col < p.N) {
                     float v = acc[i][j][r] * alpha;
-                    if (p.bias) v += p.bias[col];
                     float* o = Obase + ooff + col;
-                    if (p.accumulate) v += *o;
+                    if (!partial) {
+                        if (p.bias) v += p.bias[col];
+                        if (p.accumulate) v += *o;
+                    }
                     *o = v;
                 }
             }
@@ -365,10 +408,26 @@ __global__ __launch_bounds__(256) void nn_kernel(const NNParams p) {
     }
 }
 
+// out[i] = alpha * sum_z slabs[z][i] (+ bias[i % N]) (+ out[i])
+__global__ __launch_bounds__(256) void nn_slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                             const float* __restrict__ bias, const float* alpha_p,
+                                                             int64_t n, int N, int splitk, int64_t slab,
+                                                             int accumulate) {
+    const float alpha = alpha_p ? *alpha_p : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < splitk; ++z) s += ws[(int64_t)z * slab + i];
+        s *= alpha;
+        if (bias) s += bias[i % N];
+        if (accumulate) s += out[i];
+        out[i] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
-// TN kernel: out[tap][ca][cb] = sum_rows A(row, tap)[ca] * Bv(row)[cb]
+// TN kernel: out[(tap, ca)][cb] = sum_rows A(row, tap)[ca] * Bv(row)[cb]   (taps flattened into M)
 // ------------------------------------------------------------------------------------------
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void tn_kernel(const TNParams p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -383,10 +442,9 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const Gather& g = p.g;
 
-    const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
-    const int ca0 = tile_m * BM, cb0 = tile_n * BN;
-    const int tap = blockIdx.y;
-    const int kh = tap / g.k, kw = tap % g.k;
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    const int mf0 = tile_m * BM, cb0 = tile_n * BN;
     const int zb = blockIdx.z / p.splitk, zs = blockIdx.z % p.splitk;
 
     const float* Abase = p.A + (int64_t)zb * p.strideA;
@@ -394,7 +452,23 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNParams p) {
 
     const int row_begin = zs * p.rows_per_split;
     const int row_end = min(p.M, row_begin + p.rows_per_split);
-    const int niter = (row_end - row_begin + BKT - 1) / BKT;
+    const int niter = max(0, (row_end - row_begin + BKT - 1) / BKT);
+
+    // per-thread A-load columns: flat row mf -> (tap, channel); fixed for the whole K loop
+    int a_kh[ALOADS], a_kw[ALOADS], a_c[ALOADS];
+#pragma unroll
+    for (int i = 0; i < ALOADS; ++i) {
+        const int idx = t + 256 * i;
+        const int mf = mf0 + (idx % (BM / 4)) * 4;
+        int tap = 0, c = mf;
+        if (MODE != GATHER_PLAIN) {
+            tap = mf / p.Ca;
+            c = mf - tap * p.Ca;
+        }
+        a_kh[i] = tap / g.k;
+        a_kw[i] = tap % g.k;
+        a_c[i] = (mf < p.Mf) ? c : -1;
+    }
 
     float4 ra[ALOADS], rb[BLOADS];
     int l_row = row_begin;
@@ -403,14 +477,38 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNParams p) {
 #pragma unroll
         for (int i = 0; i < ALOADS; ++i) {
             const int idx = t + 256 * i;
-            const int kr = idx / (BM / 4), cq = (idx % (BM / 4)) * 4;
+            const int kr = idx / (BM / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int m = l_row + kr;
             if (idx < BKT * BM / 4 && m < row_end) {
-                RowPos rp = decompose_row(g, m, p.M, 0, 0);
-                int64_t off[1];
-                tap_sources<false>(g, rp, kh, kw, off);
-                v = load_chan4(Abase, off[0], ca0 + cq, p.Ca, p.a_vec);
+                RowPos rp = decompose_row<MODE>(g, m, p.M, 0, 0);
+                if (VEC) {
+                    if (a_c[i] >= 0) {
+                        int64_t off[1];
+                        tap_sources<MODE, false>(g, rp, a_kh[i], a_kw[i], off);
+                        v = load_chan4<true>(Abase, off[0], a_c[i], p.Ca);
+                    }
+                } else {
+                    // scalar path (Ca % 4 != 0): every element may belong to a different tap
+                    const int mf = mf0 + (idx % (BM / 4)) * 4;
+                    float e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        e[j] = 0.f;
+                        const int mj = mf + j;
+                        if (mj < p.Mf) {
+                            int tap = 0, c = mj;
+                            if (MODE != GATHER_PLAIN) {
+                                tap = mj / p.Ca;
+                                c = mj - tap * p.Ca;
+                            }
+                            int64_t off[1];
+                            tap_sources<MODE, false>(g, rp, tap / g.k, tap % g.k, off);
+                            if (off[0] >= 0) e[j] = Abase[off[0] + c];
+                        }
+                    }
+                    v = make_float4(e[0], e[1], e[2], e[3]);
+                }
             }
             ra[i] = v;
         }
@@ -420,8 +518,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNParams p) {
             const int kr = idx / (BN / 4), cq = (idx % (BN / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int m = l_row + kr;
-            if (idx < BKT * BN / 4 && m < row_end)
-                v = load_chan4(Bbase, (int64_t)m * p.b_ld, cb0 + cq, p.Cb, p.b_vec);
+            if (idx < BKT * BN / 4 && m < row_end) v = load_chan4<VEC>(Bbase, (int64_t)m * p.b_ld, cb0 + cq, p.Cb);
             rb[i] = v;
         }
         l_row += BKT;
@@ -465,33 +562,19 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNParams p) {
     for (int it = 0; it < niter; ++it) {
         const int cur = it & 1;
         if (it + 1 < niter) load_tile();
-        const float* as = As[cur];
-        const float* bs = Bs[cur];
-#pragma unroll
-        for (int kk = 0; kk < BKT / 2; ++kk) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[a_rd + 2 * kk * LDA + 32 * i];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[b_rd + 2 * kk * LDB + 32 * j];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+        mma_tile<TM, TN, LDA, LDB>(As[cur], Bs[cur], a_rd, b_rd, acc);
         if (it + 1 < niter) store_tile(cur ^ 1);
         __syncthreads();
     }
 
     const float alpha = p.alpha ? *p.alpha : 1.0f;
-    float* obase = p.out + (int64_t)zb * p.strideC + (int64_t)zs * p.slab_stride + (int64_t)tap * p.out_tap_stride;
+    float* obase = p.out + (int64_t)zb * p.strideC + (int64_t)zs * p.slab_stride;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = ca0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row >= p.Ca) continue;
+            const int row = mf0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= p.Mf) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = cb0 + wn * 32 * TN + 32 * j + (lane & 31);
@@ -504,7 +587,13 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNParams p) {
 // sum split-K slabs: out[i] = sum_z ws[z*slab + i]
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                           int64_t n, int splitk, int64_t slab) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < splitk; ++z) add4(s, ld4(ws + (int64_t)z * slab + i * 4));
+        *reinterpret_cast<float4*>(out + i * 4) = s;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float s = 0.f;
         for (int z = 0; z < splitk; ++z) s += ws[(int64_t)z * slab + i];
         out[i] = s;
@@ -516,79 +605,118 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <int TM, int TN, int WM, int WN>
-static void launch_nn_cfg(const NNParams& p0, bool bt, bool mirror, int zdim, hipStream_t s) {
-    NNParams p = p0;
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    const int tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
-    dim3 grid(tiles_m * p.tiles_n, 1, zdim);
-    if (bt) {
-        if (mirror)
-            hipLaunchKernelGGL((nn_kernel<TM, TN, WM, WN, true, true>), grid, dim3(256), 0, s, p);
-        else
-            hipLaunchKernelGGL((nn_kernel<TM, TN, WM, WN, true, false>), grid, dim3(256), 0, s, p);
-    } else {
-        if (mirror)
-            hipLaunchKernelGGL((nn_kernel<TM, TN, WM, WN, false, true>), grid, dim3(256), 0, s, p);
-        else
-            hipLaunchKernelGGL((nn_kernel<TM, TN, WM, WN, false, false>), grid, dim3(256), 0, s, p);
-    }
-}
+struct NNPlan {
+    int bm, bn, splitk;
+};
 
-// tile choice: largest tile that still yields >= ~1.5 waves of blocks over the 256 CUs
-static int launch_nn(NNParams& p, bool bt, bool mirror, int zdim, hipStream_t s) {
-    auto blocks = [&](int bm, int bn) {
-        return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * zdim;
-    };
+// tile: the largest that still fills the 256 CUs; split K when even the smallest cannot
+static NNPlan plan_nn(int64_t M, int N, int zdim, int niter_min, bool allow_split) {
+    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * zdim; };
+    NNPlan pl;
+    pl.splitk = 1;
     const int64_t want = 384;
-    if (p.N <= 32) {
-        launch_nn_cfg<1, 1, 4, 1>(p, bt, mirror, zdim, s);        // 128 x 32
-    } else if (p.N <= 64) {
-        if (blocks(128, 64) >= want)
-            launch_nn_cfg<2, 1, 2, 2>(p, bt, mirror, zdim, s);    // 128 x 64
-        else
-            launch_nn_cfg<1, 1, 2, 2>(p, bt, mirror, zdim, s);    // 64 x 64
+    if (N <= 32) {
+        pl.bm = 128; pl.bn = 32;
+    } else if (N <= 64) {
+        pl.bn = 64;
+        pl.bm = blocks(128, 64) >= want ? 128 : 64;
+    } else if (blocks(128, 128) >= want) {
+        pl.bm = 128; pl.bn = 128;
+    } else if (blocks(128, 64) >= want) {
+        pl.bm = 128; pl.bn = 64;
+    } else if (allow_split && niter_min >= 32) {
+        // few output tiles but a long K (4x4 / 8x8 feature maps, wide dense layers): keep the
+        // efficient 128x128 tile and split K over blockIdx.z instead of shrinking the tile
+        pl.bm = 128; pl.bn = 128;
+        const int64_t b = blocks(128, 128);
+        int sk = (int)((768 + b - 1) / b);
+        if (sk > niter_min / 8) sk = niter_min / 8;
+        if (sk > 32) sk = 32;
+        if (sk < 1) sk = 1;
+        pl.splitk = sk;
     } else {
-        if (blocks(128, 128) >= want)
-            launch_nn_cfg<2, 2, 2, 2>(p, bt, mirror, zdim, s);    // 128 x 128
-        else if (blocks(128, 64) >= want)
-            launch_nn_cfg<2, 1, 2, 2>(p, bt, mirror, zdim, s);    // 128 x 64
-        else
-            launch_nn_cfg<1, 1, 2, 2>(p, bt, mirror, zdim, s);    // 64 x 64
+        pl.bm = 64; pl.bn = 64;
     }
-    BG_LAUNCH_CHECK();
-    return BG_OK;
+    return pl;
 }
 
-template <int TM, int TN, int WM, int WN>
-static void launch_tn_cfg(const TNParams& p0, int taps, hipStream_t s) {
-    TNParams p = p0;
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    const int tiles_m = (p.Ca + BM - 1) / BM;
-    p.tiles_n = (p.Cb + BN - 1) / BN;
-    dim3 grid(tiles_m * p.tiles_n, taps, p.batch * p.splitk);
-    hipLaunchKernelGGL((tn_kernel<TM, TN, WM, WN>), grid, dim3(256), 0, s, p);
+template <int TM, int TN, int WM, int WN, bool BT, int MODE, bool MIRROR>
+static void launch_nn_inst(const NNParams& p, bool vec, dim3 grid, hipStream_t s) {
+    if (vec)
+        hipLaunchKernelGGL((nn_kernel<TM, TN, WM, WN, BT, MODE, MIRROR, true>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((nn_kernel<TM, TN, WM, WN, BT, MODE, MIRROR, false>), grid, dim3(256), 0, s, p);
+}
+
+template <bool BT, int MODE, bool MIRROR>
+static void launch_nn_tile(NNParams& p, const NNPlan& pl, bool vec, int zdim, hipStream_t s) {
+    p.tiles_m = (p.M + pl.bm - 1) / pl.bm;
+    p.tiles_n = (p.N + pl.bn - 1) / pl.bn;
+    dim3 grid(p.tiles_m * p.tiles_n, 1, zdim * p.splitk);
+    if (pl.bm == 128 && pl.bn == 128)
+        launch_nn_inst<2, 2, 2, 2, BT, MODE, MIRROR>(p, vec, grid, s);
+    else if (pl.bm == 128 && pl.bn == 64)
+        launch_nn_inst<2, 1, 2, 2, BT, MODE, MIRROR>(p, vec, grid, s);
+    else if (pl.bm == 64 && pl.bn == 64)
+        launch_nn_inst<1, 1, 2, 2, BT, MODE, MIRROR>(p, vec, grid, s);
+    else
+        launch_nn_inst<1, 1, 4, 1, BT, MODE, MIRROR>(p, vec, grid, s);
+}
+
+static size_t nn_workspace_bytes(int64_t M, int N, int zdim, int niter_min, int64_t out_elems) {
+    NNPlan pl = plan_nn(M, N, zdim, niter_min, true);
+    return pl.splitk > 1 ? (size_t)pl.splitk * out_elems * sizeof(float) : 0;
+}
+
+// the (MODE, BT) pairs that exist: CONV/BT0, TCONV/BT1 (+MIRROR), PLAIN/BT0, PLAIN/BT1
+static int launch_nn(NNParams& p, int mode, bool bt, bool mirror, bool vec, int zdim, int niter_min,
+                     int64_t out_elems, bool out_dense, void* ws, size_t ws_bytes, hipStream_t s) {
+    NNPlan pl = plan_nn(p.M, p.N, zdim, niter_min, out_dense && ws != nullptr);
+    if (pl.splitk > 1 && ws_bytes < (size_t)pl.splitk * out_elems * sizeof(float)) {
+        pl = plan_nn(p.M, p.N, zdim, niter_min, false);
+    }
+    p.splitk = pl.splitk;
+    p.slabs = reinterpret_cast<float*>(ws);
+    p.slab_stride = out_elems;
+    if (mode == GATHER_CONV)
+        launch_nn_tile<false, GATHER_CONV, false>(p, pl, vec, zdim, s);
+    else if (mode == GATHER_TCONV && mirror)
+        launch_nn_tile<true, GATHER_TCONV, true>(p, pl, vec, zdim, s);
+    else if (mode == GATHER_TCONV)
+        launch_nn_tile<true, GATHER_TCONV, false>(p, pl, vec, zdim, s);
+    else if (bt)
+        launch_nn_tile<true, GATHER_PLAIN, false>(p, pl, vec, zdim, s);
+    else
+        launch_nn_tile<false, GATHER_PLAIN, false>(p, pl, vec, zdim, s);
+    BG_LAUNCH_CHECK();
+    if (pl.splitk > 1) {
+        int blocks = (int)((out_elems + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(nn_slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slabs, p.out, p.bias, p.alpha,
+                           out_elems, p.N, pl.splitk, out_elems, p.accumulate);
+        BG_LAUNCH_CHECK();
+    }
+    return BG_OK;
 }
 
 struct TNPlan {
     int bm, bn, splitk, rows_per_split;
 };
 
-static TNPlan plan_tn(int Ca, int Cb, int taps, int batch, int M) {
+static TNPlan plan_tn(int Mf, int Cb, int batch, int M) {
     TNPlan pl;
     // available tiles: (128,128) (128,64) (64,64) (128,32)
     if (Cb <= 32) { pl.bm = 128; pl.bn = 32; }
-    else if (Cb <= 64) { pl.bn = 64; pl.bm = Ca <= 64 ? 64 : 128; }
-    else if (Ca <= 64) { pl.bm = 64; pl.bn = 64; }
+    else if (Cb <= 64) { pl.bn = 64; pl.bm = Mf <= 64 ? 64 : 128; }
+    else if (Mf <= 64) { pl.bm = 64; pl.bn = 64; }
     else { pl.bm = 128; pl.bn = 128; }
-    const int64_t tiles = (int64_t)((Ca + pl.bm - 1) / pl.bm) * ((Cb + pl.bn - 1) / pl.bn) * taps * batch;
-    int64_t want = 512;
+    const int64_t tiles = (int64_t)((Mf + pl.bm - 1) / pl.bm) * ((Cb + pl.bn - 1) / pl.bn) * batch;
+    int64_t want = 768;
     int sk = (int)((want + tiles - 1) / tiles);
-    const int max_sk = (M + 4 * BKT - 1) / (4 * BKT);      // at least 64 rows per split
+    const int max_sk = (M + 8 * BKT - 1) / (8 * BKT);      // at least 128 rows per split
     if (sk > max_sk) sk = max_sk;
     if (sk < 1) sk = 1;
-    if (sk > 256) sk = 256;
+    if (sk > 512) sk = 512;
     int rps = (M + sk - 1) / sk;
     rps = (rps + BKT - 1) / BKT * BKT;
     sk = (M + rps - 1) / rps;
@@ -597,19 +725,33 @@ static TNPlan plan_tn(int Ca, int Cb, int taps, int batch, int M) {
     return pl;
 }
 
-static size_t tn_workspace_bytes(int Ca, int Cb, int taps, int batch, int M) {
-    TNPlan pl = plan_tn(Ca, Cb, taps, batch, M);
+static size_t tn_workspace_bytes(int Mf, int Cb, int batch, int M) {
+    TNPlan pl = plan_tn(Mf, Cb, batch, M);
     if (pl.splitk <= 1) return 0;
-    return (size_t)pl.splitk * taps * Ca * Cb * batch * sizeof(float);
+    return (size_t)pl.splitk * Mf * Cb * batch * sizeof(float);
 }
 
-// out layout contiguous [batch][taps][Ca][Cb] required when split-K is used
-static int launch_tn(TNParams& p, int taps, float* final_out, void* ws, size_t ws_bytes, hipStream_t s) {
-    TNPlan pl = plan_tn(p.Ca, p.Cb, taps, p.batch, p.M);
-    const int64_t total = (int64_t)p.batch * taps * p.Ca * p.Cb;
-    const bool contiguous = (p.out_ld == p.Cb) && (p.out_tap_stride == (int64_t)p.Ca * p.Cb) &&
-                            (p.batch == 1 || p.strideC == (int64_t)taps * p.Ca * p.Cb);
-    if (pl.splitk > 1 && (!contiguous || ws == nullptr || ws_bytes < (size_t)pl.splitk * total * sizeof(float))) {
+template <int TM, int TN, int WM, int WN>
+static void launch_tn_inst(const TNParams& p, int mode, bool vec, dim3 grid, hipStream_t s) {
+    if (mode == GATHER_PLAIN) {
+        if (vec)
+            hipLaunchKernelGGL((tn_kernel<TM, TN, WM, WN, GATHER_PLAIN, true>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((tn_kernel<TM, TN, WM, WN, GATHER_PLAIN, false>), grid, dim3(256), 0, s, p);
+    } else {
+        if (vec)
+            hipLaunchKernelGGL((tn_kernel<TM, TN, WM, WN, GATHER_CONV, true>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((tn_kernel<TM, TN, WM, WN, GATHER_CONV, false>), grid, dim3(256), 0, s, p);
+    }
+}
+
+// out must be a dense [batch][Mf][Cb] block when split-K is used
+static int launch_tn(TNParams& p, int mode, bool vec, float* final_out, void* ws, size_t ws_bytes, hipStream_t s) {
+    TNPlan pl = plan_tn(p.Mf, p.Cb, p.batch, p.M);
+    const int64_t total = (int64_t)p.batch * p.Mf * p.Cb;
+    const bool dense = (p.out_ld == p.Cb) && (p.batch == 1 || p.strideC == (int64_t)p.Mf * p.Cb);
+    if (pl.splitk > 1 && (!dense || ws == nullptr || ws_bytes < (size_t)pl.splitk * total * sizeof(float))) {
         pl.splitk = 1;
         pl.rows_per_split = (p.M + BKT - 1) / BKT * BKT;
     }
@@ -622,18 +764,22 @@ static int launch_tn(TNParams& p, int taps, float* final_out, void* ws, size_t w
         p.out = final_out;
         p.slab_stride = 0;
     }
+    p.tiles_m = (p.Mf + pl.bm - 1) / pl.bm;
+    p.tiles_n = (p.Cb + pl.bn - 1) / pl.bn;
+    dim3 grid(p.tiles_m * p.tiles_n, 1, p.batch * p.splitk);
     if (pl.bm == 128 && pl.bn == 128)
-        launch_tn_cfg<2, 2, 2, 2>(p, taps, s);
+        launch_tn_inst<2, 2, 2, 2>(p, mode, vec, grid, s);
     else if (pl.bm == 128 && pl.bn == 64)
-        launch_tn_cfg<2, 1, 2, 2>(p, taps, s);
+        launch_tn_inst<2, 1, 2, 2>(p, mode, vec, grid, s);
     else if (pl.bm == 64 && pl.bn == 64)
-        launch_tn_cfg<1, 1, 2, 2>(p, taps, s);
+        launch_tn_inst<1, 1, 2, 2>(p, mode, vec, grid, s);
     else
-        launch_tn_cfg<1, 1, 4, 1>(p, taps, s);     // 128 x 32
+        launch_tn_inst<1, 1, 4, 1>(p, mode, vec, grid, s);     // 128 x 32
     BG_LAUNCH_CHECK();
     if (pl.splitk > 1) {
-        int blocks = (int)((total + 255) / 256);
+        int blocks = (int)((total / 4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(ws),
                            final_out, total, pl.splitk, total);
         BG_LAUNCH_CHECK();
@@ -658,11 +804,9 @@ static int check_conv(const BgConvDesc* d) {
     int rc = check_desc(d);
     if (rc) return rc;
     BG_REQUIRE(d->pad_mode == BG_PAD_ZERO || d->pad_lo < d->H, "reflect padding wider than the image");
-    // every output window must start inside the (low-)padded image
     BG_REQUIRE((d->Ho - 1) * d->stride - d->pad_lo < d->H && (d->Wo - 1) * d->stride - d->pad_lo < d->W,
                "conv output extent inconsistent with input");
     if (d->pad_mode == BG_PAD_REFLECT) {
-        // highest padded index read must reflect into range
         const int hi_h = (d->Ho - 1) * d->stride + d->k - 1 - d->pad_lo;
         const int hi_w = (d->Wo - 1) * d->stride + d->k - 1 - d->pad_lo;
         BG_REQUIRE(hi_h <= 2 * (d->H - 1) && hi_w <= 2 * (d->W - 1), "reflect padding out of range");
@@ -694,59 +838,110 @@ static double conv_flops(const BgConvDesc* d, bool deconv) {
     return 2.0 * px * d->k * d->k * d->Cin * d->Cout;
 }
 
+static inline int kc_of(int C) { return (C + BKT - 1) / BKT; }
+
+// ---- parameter builders shared by the entry points and their workspace queries ----
+static void conv_fwd_params(const BgConvDesc* d, NNParams& p) {
+    memset(&p, 0, sizeof(p));
+    Gather& g = p.g;
+    g.Nb = d->N; g.Hs = d->H; g.Ws = d->W; g.Ho = d->Ho; g.Wo = d->Wo; g.Hq = d->Ho; g.Wq = d->Wo; g.pstep = 1;
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.reflect = d->pad_mode == BG_PAD_REFLECT; g.ld = d->Cin;
+    p.C = d->Cin; p.M = d->N * d->Ho * d->Wo; p.N = d->Cout;
+    p.tap_stride = (int64_t)d->Cin * d->Cout; p.ldk = d->Cout; p.ldn = 1;
+    p.out_ld = d->Cout; p.batch = 1;
+}
+
+static void conv_dgrad_params(const BgConvDesc* d, NNParams& p) {
+    memset(&p, 0, sizeof(p));
+    Gather& g = p.g;
+    g.Nb = d->N; g.Hs = d->Ho; g.Ws = d->Wo; g.Ho = d->H; g.Wo = d->W;
+    g.pstep = d->stride; g.Hq = d->H / d->stride; g.Wq = d->W / d->stride;
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo;
+    g.reflect = (d->pad_mode == BG_PAD_REFLECT) && d->pad_lo > 0; g.ld = d->Cout;
+    p.C = d->Cout; p.M = d->N * g.Hq * g.Wq; p.N = d->Cin;
+    p.tap_stride = (int64_t)d->Cin * d->Cout; p.ldk = 1; p.ldn = d->Cout;   // B[c=co][n=ci] = w[tap][ci][co]
+    p.out_ld = d->Cin; p.batch = 1;
+}
+
+static void deconv_fwd_params(const BgConvDesc* d, NNParams& p) {
+    memset(&p, 0, sizeof(p));
+    Gather& g = p.g;
+    g.Nb = d->N; g.Hs = d->H; g.Ws = d->W; g.Ho = d->Ho; g.Wo = d->Wo;
+    g.pstep = d->stride; g.Hq = d->Ho / d->stride; g.Wq = d->Wo / d->stride;
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.reflect = 0; g.ld = d->Cin;
+    p.C = d->Cin; p.M = d->N * g.Hq * g.Wq; p.N = d->Cout;
+    p.tap_stride = (int64_t)d->Cin * d->Cout; p.ldk = 1; p.ldn = d->Cin;    // B[c=ci][n=co] = w[tap][co][ci]
+    p.out_ld = d->Cout; p.batch = 1;
+}
+
+static void deconv_dgrad_params(const BgConvDesc* d, NNParams& p) {
+    memset(&p, 0, sizeof(p));
+    Gather& g = p.g;
+    g.Nb = d->N; g.Hs = d->Ho; g.Ws = d->Wo; g.Ho = d->H; g.Wo = d->W; g.Hq = d->H; g.Wq = d->W; g.pstep = 1;
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.reflect = 0; g.ld = d->Cout;
+    p.C = d->Cout; p.M = d->N * d->H * d->W; p.N = d->Cin;
+    p.tap_stride = (int64_t)d->Cin * d->Cout; p.ldk = d->Cin; p.ldn = 1;    // B[c=co][n=ci] = w[tap][co][ci]
+    p.out_ld = d->Cin; p.batch = 1;
+}
+
+// fewest K iterations over the phases of a transposed gather (k3 s2 has 1x1 .. 2x2 taps per phase)
+static int tconv_min_iters(const BgConvDesc* d, int C) {
+    int per_axis = d->stride == 1 ? d->k : d->k / d->stride;   // smallest tap count of a phase
+    if (per_axis < 1) per_axis = 1;
+    return per_axis * per_axis * kc_of(C);
+}
+
 }  // namespace bg
 
 using namespace bg;
 
 extern "C" {
 
+size_t bg_conv2d_fwd_workspace_bytes(const BgConvDesc* d) {
+    if (!d) return 0;
+    return nn_workspace_bytes((int64_t)d->N * d->Ho * d->Wo, d->Cout, 1, d->k * d->k * kc_of(d->Cin),
+                              (int64_t)d->N * d->Ho * d->Wo * d->Cout);
+}
+
 int bg_conv2d_fwd(const BgConvDesc* d, const float* x, const float* w, const float* bias, const float* alpha_dev,
-                  float* y, int accumulate, void* stream) {
+                  float* y, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_conv(d);
     if (rc) return rc;
     NNParams p;
-    memset(&p, 0, sizeof(p));
-    p.A = x; p.B = w; p.bias = bias; p.alpha = alpha_dev; p.out = y;
-    Gather& g = p.g;
-    g.Nb = d->N; g.Hs = d->H; g.Ws = d->W; g.Ho = d->Ho; g.Wo = d->Wo; g.Hq = d->Ho; g.Wq = d->Wo; g.pstep = 1;
-    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.mode = GATHER_CONV;
-    g.reflect = d->pad_mode == BG_PAD_REFLECT; g.plain = 0; g.ld = d->Cin;
-    p.C = d->Cin; p.M = d->N * d->Ho * d->Wo; p.N = d->Cout;
-    p.tap_stride = (int64_t)d->Cin * d->Cout; p.ldk = d->Cout; p.ldn = 1;
-    p.out_ld = d->Cout; p.accumulate = accumulate; p.batch = 1;
-    p.a_vec = (d->Cin % 4 == 0) && aligned16(x);
-    p.b_vec = (d->Cout % 4 == 0) && aligned16(w);
+    conv_fwd_params(d, p);
+    p.A = x; p.B = w; p.bias = bias; p.alpha = alpha_dev; p.out = y; p.accumulate = accumulate;
+    const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
     Tag tag("conv2d_fwd", d);
     ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
-    return launch_nn(p, false, false, 1, as_stream(stream));
+    return launch_nn(p, GATHER_CONV, false, false, vec, 1, d->k * d->k * kc_of(d->Cin),
+                     (int64_t)p.M * d->Cout, true, ws, ws_bytes, as_stream(stream));
+}
+
+size_t bg_conv2d_dgrad_workspace_bytes(const BgConvDesc* d) {
+    if (!d) return 0;
+    const int z = d->stride * d->stride;
+    return nn_workspace_bytes((int64_t)d->N * (d->H / d->stride) * (d->W / d->stride), d->Cin, z,
+                              tconv_min_iters(d, d->Cout), (int64_t)d->N * d->H * d->W * d->Cin);
 }
 
 int bg_conv2d_dgrad(const BgConvDesc* d, const float* dy, const float* w, const float* alpha_dev, float* dx,
-                    int accumulate, void* stream) {
+                    int accumulate, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_conv(d);
     if (rc) return rc;
     BG_REQUIRE(d->H % d->stride == 0 && d->W % d->stride == 0, "conv dgrad: H,W must be multiples of stride");
     NNParams p;
-    memset(&p, 0, sizeof(p));
-    p.A = dy; p.B = w; p.bias = nullptr; p.alpha = alpha_dev; p.out = dx;
-    Gather& g = p.g;
-    g.Nb = d->N; g.Hs = d->Ho; g.Ws = d->Wo; g.Ho = d->H; g.Wo = d->W;
-    g.pstep = d->stride; g.Hq = d->H / d->stride; g.Wq = d->W / d->stride;
-    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.mode = GATHER_TCONV;
-    g.reflect = (d->pad_mode == BG_PAD_REFLECT) && d->pad_lo > 0; g.plain = 0; g.ld = d->Cout;
-    p.C = d->Cout; p.M = d->N * g.Hq * g.Wq; p.N = d->Cin;
-    p.tap_stride = (int64_t)d->Cin * d->Cout; p.ldk = 1; p.ldn = d->Cout;   // B[c=co][n=ci] = w[tap][ci][co]
-    p.out_ld = d->Cin; p.accumulate = accumulate; p.batch = 1;
-    p.a_vec = (d->Cout % 4 == 0) && aligned16(dy);
-    p.b_vec = (d->Cout % 4 == 0) && aligned16(w);
+    conv_dgrad_params(d, p);
+    p.A = dy; p.B = w; p.alpha = alpha_dev; p.out = dx; p.accumulate = accumulate;
+    const bool vec = (d->Cout % 4 == 0) && aligned16(dy) && aligned16(w);
     Tag tag("conv2d_dgrad", d);
     ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
-    return launch_nn(p, true, g.reflect != 0, d->stride * d->stride, as_stream(stream));
+    return launch_nn(p, GATHER_TCONV, true, p.g.reflect != 0, vec, d->stride * d->stride, tconv_min_iters(d, d->Cout),
+                     (int64_t)d->N * d->H * d->W * d->Cin, true, ws, ws_bytes, as_stream(stream));
 }
 
 size_t bg_conv2d_wgrad_workspace_bytes(const BgConvDesc* d) {
     if (!d) return 0;
-    return tn_workspace_bytes(d->Cin, d->Cout, d->k * d->k, 1, d->N * d->Ho * d->Wo);
+    return tn_workspace_bytes(d->k * d->k * d->Cin, d->Cout, 1, d->N * d->Ho * d->Wo);
 }
 
 int bg_conv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
@@ -758,63 +953,59 @@ int bg_conv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, float*
     p.A = x; p.Bv = dy;
     Gather& g = p.g;
     g.Nb = d->N; g.Hs = d->H; g.Ws = d->W; g.Ho = d->Ho; g.Wo = d->Wo; g.Hq = d->Ho; g.Wq = d->Wo; g.pstep = 1;
-    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.mode = GATHER_CONV;
-    g.reflect = d->pad_mode == BG_PAD_REFLECT; g.plain = 0; g.ld = d->Cin;
-    p.Ca = d->Cin; p.Cb = d->Cout; p.b_ld = d->Cout; p.M = d->N * d->Ho * d->Wo;
-    p.out_ld = d->Cout; p.out_tap_stride = (int64_t)d->Cin * d->Cout; p.batch = 1;
-    p.a_vec = (d->Cin % 4 == 0) && aligned16(x);
-    p.b_vec = (d->Cout % 4 == 0) && aligned16(dy);
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.reflect = d->pad_mode == BG_PAD_REFLECT; g.ld = d->Cin;
+    p.Ca = d->Cin; p.Cb = d->Cout; p.Mf = d->k * d->k * d->Cin; p.b_ld = d->Cout; p.M = d->N * d->Ho * d->Wo;
+    p.out_ld = d->Cout; p.batch = 1;
+    const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(dy);
     Tag tag("conv2d_wgrad", d);
     ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
-    return launch_tn(p, d->k * d->k, dw, ws, ws_bytes, as_stream(stream));
+    return launch_tn(p, GATHER_CONV, vec, dw, ws, ws_bytes, as_stream(stream));
+}
+
+size_t bg_deconv2d_fwd_workspace_bytes(const BgConvDesc* d) {
+    if (!d) return 0;
+    const int z = d->stride * d->stride;
+    return nn_workspace_bytes((int64_t)d->N * d->H * d->W, d->Cout, z, tconv_min_iters(d, d->Cin),
+                              (int64_t)d->N * d->Ho * d->Wo * d->Cout);
 }
 
 int bg_deconv2d_fwd(const BgConvDesc* d, const float* x, const float* w, const float* bias, const float* alpha_dev,
-                    float* y, int accumulate, void* stream) {
+                    float* y, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_deconv(d);
     if (rc) return rc;
     NNParams p;
-    memset(&p, 0, sizeof(p));
-    p.A = x; p.B = w; p.bias = bias; p.alpha = alpha_dev; p.out = y;
-    Gather& g = p.g;
-    g.Nb = d->N; g.Hs = d->H; g.Ws = d->W; g.Ho = d->Ho; g.Wo = d->Wo;
-    g.pstep = d->stride; g.Hq = d->Ho / d->stride; g.Wq = d->Wo / d->stride;
-    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.mode = GATHER_TCONV; g.reflect = 0; g.plain = 0;
-    g.ld = d->Cin;
-    p.C = d->Cin; p.M = d->N * g.Hq * g.Wq; p.N = d->Cout;
-    p.tap_stride = (int64_t)d->Cin * d->Cout; p.ldk = 1; p.ldn = d->Cin;    // B[c=ci][n=co] = w[tap][co][ci]
-    p.out_ld = d->Cout; p.accumulate = accumulate; p.batch = 1;
-    p.a_vec = (d->Cin % 4 == 0) && aligned16(x);
-    p.b_vec = (d->Cin % 4 == 0) && aligned16(w);
+    deconv_fwd_params(d, p);
+    p.A = x; p.B = w; p.bias = bias; p.alpha = alpha_dev; p.out = y; p.accumulate = accumulate;
+    const bool vec = (d->Cin % 4 == 0) && aligned16(x) && aligned16(w);
     Tag tag("deconv2d_fwd", d);
     ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
-    return launch_nn(p, true, false, d->stride * d->stride, as_stream(stream));
+    return launch_nn(p, GATHER_TCONV, true, false, vec, d->stride * d->stride, tconv_min_iters(d, d->Cin),
+                     (int64_t)d->N * d->Ho * d->Wo * d->Cout, true, ws, ws_bytes, as_stream(stream));
+}
+
+size_t bg_deconv2d_dgrad_workspace_bytes(const BgConvDesc* d) {
+    if (!d) return 0;
+    return nn_workspace_bytes((int64_t)d->N * d->H * d->W, d->Cin, 1, d->k * d->k * kc_of(d->Cout),
+                              (int64_t)d->N * d->H * d->W * d->Cin);
 }
 
 int bg_deconv2d_dgrad(const BgConvDesc* d, const float* dy, const float* w, const float* alpha_dev, float* dx,
-                      int accumulate, void* stream) {
+                      int accumulate, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_deconv(d);
     if (rc) return rc;
     NNParams p;
-    memset(&p, 0, sizeof(p));
-    p.A = dy; p.B = w; p.bias = nullptr; p.alpha = alpha_dev; p.out = dx;
-    Gather& g = p.g;
-    g.Nb = d->N; g.Hs = d->Ho; g.Ws = d->Wo; g.Ho = d->H; g.Wo = d->W; g.Hq = d->H; g.Wq = d->W; g.pstep = 1;
-    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.mode = GATHER_CONV; g.reflect = 0; g.plain = 0;
-    g.ld = d->Cout;
-    p.C = d->Cout; p.M = d->N * d->H * d->W; p.N = d->Cin;
-    p.tap_stride = (int64_t)d->Cin * d->Cout; p.ldk = d->Cin; p.ldn = 1;    // B[c=co][n=ci] = w[tap][co][ci]
-    p.out_ld = d->Cin; p.accumulate = accumulate; p.batch = 1;
-    p.a_vec = (d->Cout % 4 == 0) && aligned16(dy);
-    p.b_vec = (d->Cin % 4 == 0) && aligned16(w);
+    deconv_dgrad_params(d, p);
+    p.A = dy; p.B = w; p.alpha = alpha_dev; p.out = dx; p.accumulate = accumulate;
+    const bool vec = (d->Cout % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy) && aligned16(w);
     Tag tag("deconv2d_dgrad", d);
     ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
-    return launch_nn(p, false, false, 1, as_stream(stream));
+    return launch_nn(p, GATHER_CONV, false, false, vec, 1, d->k * d->k * kc_of(d->Cout),
+                     (int64_t)p.M * d->Cin, true, ws, ws_bytes, as_stream(stream));
 }
 
 size_t bg_deconv2d_wgrad_workspace_bytes(const BgConvDesc* d) {
     if (!d) return 0;
-    return tn_workspace_bytes(d->Cout, d->Cin, d->k * d->k, 1, d->N * d->H * d->W);
+    return tn_workspace_bytes(d->k * d->k * d->Cout, d->Cin, 1, d->N * d->H * d->W);
 }
 
 int bg_deconv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
@@ -827,20 +1018,21 @@ int bg_deconv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, floa
     p.A = dy; p.Bv = x;
     Gather& g = p.g;
     g.Nb = d->N; g.Hs = d->Ho; g.Ws = d->Wo; g.Ho = d->H; g.Wo = d->W; g.Hq = d->H; g.Wq = d->W; g.pstep = 1;
-    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.mode = GATHER_CONV; g.reflect = 0; g.plain = 0;
-    g.ld = d->Cout;
-    p.Ca = d->Cout; p.Cb = d->Cin; p.b_ld = d->Cin; p.M = d->N * d->H * d->W;
-    p.out_ld = d->Cin; p.out_tap_stride = (int64_t)d->Cin * d->Cout; p.batch = 1;
-    p.a_vec = (d->Cout % 4 == 0) && aligned16(dy);
-    p.b_vec = (d->Cin % 4 == 0) && aligned16(x);
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.reflect = 0; g.ld = d->Cout;
+    p.Ca = d->Cout; p.Cb = d->Cin; p.Mf = d->k * d->k * d->Cout; p.b_ld = d->Cin; p.M = d->N * d->H * d->W;
+    p.out_ld = d->Cin; p.batch = 1;
+    const bool vec = (d->Cout % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy) && aligned16(x);
     Tag tag("deconv2d_wgrad", d);
     ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
-    return launch_tn(p, d->k * d->k, dw, ws, ws_bytes, as_stream(stream));
+    return launch_tn(p, GATHER_CONV, vec, dw, ws, ws_bytes, as_stream(stream));
 }
 
 size_t bg_gemm_workspace_bytes(const BgGemmDesc* d) {
-    if (!d || !d->transA) return 0;
-    return tn_workspace_bytes(d->M, d->N, 1, d->batch > 0 ? d->batch : 1, d->K);
+    if (!d) return 0;
+    const int batch = d->batch > 0 ? d->batch : 1;
+    if (d->transA) return tn_workspace_bytes(d->M, d->N, batch, d->K);
+    if (d->ldc != d->N || batch != 1) return 0;
+    return nn_workspace_bytes(d->M, d->N, 1, kc_of(d->K), (int64_t)d->M * d->N);
 }
 
 int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bias, const float* alpha_dev,
@@ -848,25 +1040,25 @@ int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bi
     BG_REQUIRE(d != nullptr, "null BgGemmDesc");
     BG_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch >= 1, "BgGemmDesc: non-positive dimension");
     const double flops = 2.0 * d->M * d->N * d->K * d->batch;
+    Tag tag("gemm", d);
     if (!d->transA) {
         NNParams p;
         memset(&p, 0, sizeof(p));
         p.A = A; p.B = B; p.bias = bias; p.alpha = alpha_dev; p.out = C;
         Gather& g = p.g;
         g.Nb = d->M; g.Hs = 1; g.Ws = 1; g.Ho = 1; g.Wo = 1; g.Hq = 1; g.Wq = 1; g.pstep = 1;
-        g.k = 1; g.stride = 1; g.pad = 0; g.mode = GATHER_CONV; g.reflect = 0; g.plain = 1; g.ld = d->lda;
+        g.k = 1; g.stride = 1; g.pad = 0; g.reflect = 0; g.ld = d->lda;
         p.C = d->K; p.M = d->M; p.N = d->N; p.tap_stride = 0;
         if (d->transB) { p.ldk = 1; p.ldn = d->ldb; } else { p.ldk = d->ldb; p.ldn = 1; }
         p.out_ld = d->ldc; p.accumulate = accumulate; p.batch = d->batch;
         p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC;
-        p.a_vec = (d->K % 4 == 0) && (d->lda % 4 == 0) && (d->strideA % 4 == 0) && aligned16(A);
-        if (d->transB)
-            p.b_vec = (d->K % 4 == 0) && (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
-        else
-            p.b_vec = (d->N % 4 == 0) && (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
-        Tag tag("gemm", d);
+        bool vec = (d->K % 4 == 0) && (d->lda % 4 == 0) && (d->strideA % 4 == 0) && aligned16(A) &&
+                   (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
+        if (!d->transB) vec = vec && (d->N % 4 == 0);
         ProfScope prof(as_stream(stream), flops, tag.s);
-        return launch_nn(p, d->transB != 0, false, d->batch, as_stream(stream));
+        const bool dense = d->ldc == d->N && d->batch == 1;
+        return launch_nn(p, GATHER_PLAIN, d->transB != 0, false, vec, d->batch, kc_of(d->K), (int64_t)d->M * d->N,
+                         dense, dense ? ws : nullptr, ws_bytes, as_stream(stream));
     }
     BG_REQUIRE(!d->transB, "bg_gemm: transA && transB unsupported");
     BG_REQUIRE(bias == nullptr && !accumulate, "bg_gemm: transA path has no bias / accumulate");
@@ -875,17 +1067,14 @@ int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bi
     p.A = A; p.Bv = B; p.alpha = alpha_dev;
     Gather& g = p.g;
     g.Nb = d->K; g.Hs = 1; g.Ws = 1; g.Ho = 1; g.Wo = 1; g.Hq = 1; g.Wq = 1; g.pstep = 1;
-    g.k = 1; g.stride = 1; g.pad = 0; g.mode = GATHER_CONV; g.reflect = 0; g.plain = 1; g.ld = d->lda;
-    p.Ca = d->M; p.Cb = d->N; p.b_ld = d->ldb; p.M = d->K;
-    p.out_ld = d->ldc; p.out_tap_stride = 0; p.batch = d->batch;
+    g.k = 1; g.stride = 1; g.pad = 0; g.reflect = 0; g.ld = d->lda;
+    p.Ca = d->M; p.Cb = d->N; p.Mf = d->M; p.b_ld = d->ldb; p.M = d->K;
+    p.out_ld = d->ldc; p.batch = d->batch;
     p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC;
-    p.a_vec = (d->M % 4 == 0) && (d->lda % 4 == 0) && (d->strideA % 4 == 0) && aligned16(A);
-    p.b_vec = (d->N % 4 == 0) && (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
-    // out_tap_stride must describe a contiguous [Ca][Cb] tile for the split-K path
-    p.out_tap_stride = (int64_t)d->M * d->N;
-    Tag tag("gemm", d);
+    const bool vec = (d->M % 4 == 0) && (d->lda % 4 == 0) && (d->strideA % 4 == 0) && aligned16(A) &&
+                     (d->N % 4 == 0) && (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
     ProfScope prof(as_stream(stream), flops, tag.s);
-    return launch_tn(p, 1, C, ws, ws_bytes, as_stream(stream));
+    return launch_tn(p, GATHER_PLAIN, vec, C, ws, ws_bytes, as_stream(stream));
 }
 
 }  // extern "C"

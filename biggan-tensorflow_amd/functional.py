@@ -81,7 +81,9 @@ class Conv2dFn(Function):
         assert cin2 == Cin, (x.shape, w.shape)
         d = hip.conv_desc(N, H, W_, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode)
         y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-        check(lib().bg_conv2d_fwd(d, f32(x), f32(w), f32(bias), None, f32(y), 0, stream()))
+        L = lib()
+        ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, d, x.device)
+        check(L.bg_conv2d_fwd(d, f32(x), f32(w), f32(bias), None, f32(y), 0, f32(ws), nb, stream()))
         ctx.desc = d
         ctx.x, ctx.w, ctx.bias = x, w, bias
         return y
@@ -94,7 +96,8 @@ class Conv2dFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(L.bg_conv2d_dgrad(d, f32(dy), f32(w), None, f32(dx), 0, stream()))
+            ws, nb = hip.scratch(L.bg_conv2d_dgrad_workspace_bytes, d, x.device)
+            check(L.bg_conv2d_dgrad(d, f32(dy), f32(w), None, f32(dx), 0, f32(ws), nb, stream()))
 
         def wg(out):
             nb = L.bg_conv2d_wgrad_workspace_bytes(d)
@@ -126,7 +129,9 @@ class Deconv2dFn(Function):
         else:
             y = torch.empty((N, H * stride, W_ * stride, Cout), dtype=torch.float32, device=x.device)
             acc = 0
-        check(lib().bg_deconv2d_fwd(d, f32(x), f32(w), f32(bias), None, f32(y), acc, stream()))
+        L = lib()
+        ws, nb = hip.scratch(L.bg_deconv2d_fwd_workspace_bytes, d, x.device)
+        check(L.bg_deconv2d_fwd(d, f32(x), f32(w), f32(bias), None, f32(y), acc, f32(ws), nb, stream()))
         ctx.desc = d
         ctx.x, ctx.w, ctx.bias = x, w, bias
         ctx.acc = acc
@@ -140,7 +145,8 @@ class Deconv2dFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(L.bg_deconv2d_dgrad(d, f32(dy), f32(w), None, f32(dx), 0, stream()))
+            ws, nb = hip.scratch(L.bg_deconv2d_dgrad_workspace_bytes, d, x.device)
+            check(L.bg_deconv2d_dgrad(d, f32(dy), f32(w), None, f32(dx), 0, f32(ws), nb, stream()))
 
         def wg(out):
             nb = L.bg_deconv2d_wgrad_workspace_bytes(d)

@@ -37,12 +37,16 @@ SIGNATURES = {
     "bg_abi_version": (c_int, []),
     "bg_last_error": (c_char_p, []),
     "bg_target_arch": (c_char_p, []),
-    "bg_conv2d_fwd": (c_int, [_CD, _P, _P, _P, _P, _P, c_int, _P]),
-    "bg_conv2d_dgrad": (c_int, [_CD, _P, _P, _P, _P, c_int, _P]),
+    "bg_conv2d_fwd_workspace_bytes": (c_size_t, [_CD]),
+    "bg_conv2d_fwd": (c_int, [_CD, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "bg_conv2d_dgrad_workspace_bytes": (c_size_t, [_CD]),
+    "bg_conv2d_dgrad": (c_int, [_CD, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "bg_conv2d_wgrad_workspace_bytes": (c_size_t, [_CD]),
     "bg_conv2d_wgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
-    "bg_deconv2d_fwd": (c_int, [_CD, _P, _P, _P, _P, _P, c_int, _P]),
-    "bg_deconv2d_dgrad": (c_int, [_CD, _P, _P, _P, _P, c_int, _P]),
+    "bg_deconv2d_fwd_workspace_bytes": (c_size_t, [_CD]),
+    "bg_deconv2d_fwd": (c_int, [_CD, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "bg_deconv2d_dgrad_workspace_bytes": (c_size_t, [_CD]),
+    "bg_deconv2d_dgrad": (c_int, [_CD, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "bg_deconv2d_wgrad_workspace_bytes": (c_size_t, [_CD]),
     "bg_deconv2d_wgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
     "bg_gemm_workspace_bytes": (c_size_t, [_GD]),
@@ -147,3 +151,11 @@ def workspace(nbytes, device):
     """Scratch from PyTorch's caching allocator (no allocation inside the library)."""
     n = max(int(nbytes), 16)
     return torch.empty((n + 3) // 4, dtype=torch.float32, device=device)
+
+
+def scratch(query, desc, device):
+    """(ws tensor or None, nbytes) for a *_workspace_bytes query."""
+    nb = int(query(desc))
+    if nb == 0:
+        return None, 0
+    return workspace(nb, device), nb

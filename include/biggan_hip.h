@@ -48,23 +48,34 @@ typedef struct BgConvDesc {
     int32_t pad_mode;          /* BG_PAD_REFLECT (tf.pad REFLECT + VALID, ops.py:82) or BG_PAD_ZERO */
 } BgConvDesc;
 
+/* Every MFMA GEMM entry point takes caller-provided scratch (ws, ws_bytes) sized by the matching
+ * *_workspace_bytes(): it holds split-K partial slabs for layers whose output is too small to fill
+ * the chip (4x4 / 8x8 feature maps, weight gradients).  ws may be NULL: the kernel then runs
+ * un-split (same result up to fp32 summation order). */
+
 /* tf.nn.conv2d (+ reflect tf.pad, + bias_add)                       ops.py:82,94-98
  *   y = alpha * conv(x, w) [+ bias] [+ y if accumulate]; alpha_dev (nullable) is a device scalar. */
+size_t bg_conv2d_fwd_workspace_bytes(const BgConvDesc*);
 int bg_conv2d_fwd  (const BgConvDesc*, const float* x, const float* w, const float* bias,
-                    const float* alpha_dev, float* y, int accumulate, void* stream);
+                    const float* alpha_dev, float* y, int accumulate,
+                    void* ws, size_t ws_bytes, void* stream);
 /* gradient of the above w.r.t. x (reflect padding folded back)      autodiff of ops.py:82,94 */
+size_t bg_conv2d_dgrad_workspace_bytes(const BgConvDesc*);
 int bg_conv2d_dgrad(const BgConvDesc*, const float* dy, const float* w, const float* alpha_dev,
-                    float* dx, int accumulate, void* stream);
-/* gradient w.r.t. w: dw[k,k,Cin,Cout]; ws from bg_conv2d_wgrad_workspace_bytes */
+                    float* dx, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* gradient w.r.t. w: dw[k,k,Cin,Cout] */
 size_t bg_conv2d_wgrad_workspace_bytes(const BgConvDesc*);
 int bg_conv2d_wgrad(const BgConvDesc*, const float* x, const float* dy, float* dw,
                     void* ws, size_t ws_bytes, void* stream);
 
 /* tf.nn.conv2d_transpose(SAME) (+ bias_add)                          ops.py:127-132 */
+size_t bg_deconv2d_fwd_workspace_bytes(const BgConvDesc*);
 int bg_deconv2d_fwd  (const BgConvDesc*, const float* x, const float* w, const float* bias,
-                      const float* alpha_dev, float* y, int accumulate, void* stream);
+                      const float* alpha_dev, float* y, int accumulate,
+                      void* ws, size_t ws_bytes, void* stream);
+size_t bg_deconv2d_dgrad_workspace_bytes(const BgConvDesc*);
 int bg_deconv2d_dgrad(const BgConvDesc*, const float* dy, const float* w, const float* alpha_dev,
-                      float* dx, int accumulate, void* stream);
+                      float* dx, int accumulate, void* ws, size_t ws_bytes, void* stream);
 size_t bg_deconv2d_wgrad_workspace_bytes(const BgConvDesc*);
 int bg_deconv2d_wgrad(const BgConvDesc*, const float* x, const float* dy, float* dw,
                       void* ws, size_t ws_bytes, void* stream);
