@@ -279,6 +279,60 @@ __global__ __launch_bounds__(AL_BLOCK) void ortho_cosine_kernel(const float* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// ortho-cosine regulariser, low-rank form for wide kernels (rows < c, e.g. first/dense2 [184, 16384]):
+// with G = W W^T, s = W 1, P = G W (all O(rows^2 c)) the c x c Gram matrix is never formed:
+//   n_i^2 = q_i = w_i^T G w_i = sum_r W[r,i] P[r,i],  sum_k A[i,k] = t_i = w_i^T s,
+//   loss = kappa sum_i t_i^2/q_i + scale c / (2(c-1)),  kappa = scale (c-2) / (2(c-1))
+//   dW = s alpha^T + (W alpha) 1^T + 2 P diag(beta) + 2 (W diag(beta) W^T) W,
+//   alpha_i = 2 kappa t_i / q_i, beta_i = -kappa t_i^2 / q_i^2
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AL_BLOCK) void ortho_lowrank_cols_kernel(const float* __restrict__ W,
+                                                                       const float* __restrict__ P,
+                                                                       const float* __restrict__ s, float scale,
+                                                                       float* __restrict__ alpha,
+                                                                       float* __restrict__ Wb, float* loss_accum,
+                                                                       int rows, int c) {
+    __shared__ float sh[4];
+    const int i = blockIdx.x * AL_BLOCK + threadIdx.x;
+    float contrib = 0.f;
+    if (i < c) {
+        float q = 0.f, t = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            const float w = W[(int64_t)r * c + i];
+            q += w * P[(int64_t)r * c + i];
+            t += w * s[r];
+        }
+        const float kappa = c > 1 ? scale * (float)(c - 2) / (2.f * (float)(c - 1)) : 0.f;
+        const bool clamped = q < 1e-12f;
+        const float qc = fmaxf(q, 1e-12f);
+        const float a = 2.f * kappa * t / qc;
+        const float b = clamped ? 0.f : -kappa * t * t / (qc * qc);
+        alpha[i] = a;
+        contrib = kappa * t * t / qc + (c > 1 ? scale / (2.f * (float)(c - 1)) * (clamped ? 0.f : 1.f) : 0.f);
+        for (int r = 0; r < rows; ++r) Wb[(int64_t)r * c + i] = W[(int64_t)r * c + i] * b;
+        // stash beta in the first row's slot of alpha's companion: beta = Wb / W is not safe (W may be 0),
+        // so it is kept in alpha[c + i]
+        alpha[c + i] = b;
+    }
+    contrib = block_sum_256(contrib, sh);
+    if (threadIdx.x == 0) atomicAdd(loss_accum, contrib);
+}
+
+// dW = 2*T + s alpha^T + (W alpha) 1^T + 2 P diag(beta), T = (W diag(beta) W^T) W given in dW
+__global__ __launch_bounds__(AL_BLOCK) void ortho_lowrank_finish_kernel(float* __restrict__ dW,
+                                                                         const float* __restrict__ P,
+                                                                         const float* __restrict__ s,
+                                                                         const float* __restrict__ Walpha,
+                                                                         const float* __restrict__ ab, int rows,
+                                                                         int c) {
+    const int64_t n = (int64_t)rows * c;
+    for (int64_t idx = (int64_t)blockIdx.x * AL_BLOCK + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * AL_BLOCK) {
+        const int r = (int)(idx / c), i = (int)(idx % c);
+        dW[idx] = 2.f * dW[idx] + s[r] * ab[i] + Walpha[r] + 2.f * P[idx] * ab[c + i];
+    }
+}
+
 }  // namespace bg
 
 using namespace bg;
@@ -375,6 +429,26 @@ int bg_hinge_g_grad(const float* sums, double n_global, float flood, float* d_fa
     BG_REQUIRE(sums && d_fake && n > 0 && n_global > 0, "bg_hinge_g_grad: bad argument");
     hipLaunchKernelGGL(hinge_g_grad_kernel, dim3((n + AL_BLOCK - 1) / AL_BLOCK), dim3(AL_BLOCK), 0, as_stream(stream),
                        sums, n_global, flood, d_fake, loss_out, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_ortho_lowrank_cols(const float* W, const float* P, const float* s, float scale, float* alpha_beta, float* Wb,
+                          float* loss_accum, int rows, int c, void* stream) {
+    BG_REQUIRE(W && P && s && alpha_beta && Wb && loss_accum && rows > 0 && c > 0, "bg_ortho_lowrank_cols: bad argument");
+    hipLaunchKernelGGL(ortho_lowrank_cols_kernel, dim3((c + AL_BLOCK - 1) / AL_BLOCK), dim3(AL_BLOCK), 0,
+                       as_stream(stream), W, P, s, scale, alpha_beta, Wb, loss_accum, rows, c);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_ortho_lowrank_finish(float* dW, const float* P, const float* s, const float* Walpha, const float* alpha_beta,
+                            int rows, int c, void* stream) {
+    BG_REQUIRE(dW && P && s && Walpha && alpha_beta && rows > 0 && c > 0, "bg_ortho_lowrank_finish: bad argument");
+    int64_t blocks = ((int64_t)rows * c + AL_BLOCK - 1) / AL_BLOCK;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ortho_lowrank_finish_kernel, dim3((unsigned)blocks), dim3(AL_BLOCK), 0, as_stream(stream), dW,
+                       P, s, Walpha, alpha_beta, rows, c);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -515,6 +515,17 @@ __global__ __launch_bounds__(EW_BLOCK) void axpby_kernel(const float* __restrict
         y[i] = b != 0.f ? a * x[i] + b * y[i] : a * x[i];
 }
 
+__global__ __launch_bounds__(EW_BLOCK) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ y, int64_t n) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const float4 av = ldg4(a + i * 4), bv = ldg4(b + i * 4);
+        stg4(y + i * 4, make_float4(av.x + bv.x, av.y + bv.y, av.z + bv.z, av.w + bv.w));
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK)
+        y[i] = a[i] + b[i];
+}
+
 __global__ __launch_bounds__(EW_BLOCK) void scale_add_kernel(const float* __restrict__ o,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ x, float* __restrict__ y,
@@ -592,6 +603,33 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_rowdot_kernel(const float* __rest
         }
     }
     if (lane == 0 && ss != 0.f) atomicAdd(ssv, ss);
+}
+
+// out[r] = sum_c W[r][c] * v[c]   (one wave per row; v == nullptr: plain row sums)
+__global__ __launch_bounds__(EW_BLOCK) void gemv_rows_kernel(const float* __restrict__ w, const float* __restrict__ v,
+                                                              float* __restrict__ out, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    for (int r = wave; r < rows; r += nwaves) {
+        const float* wr = w + (int64_t)r * cols;
+        float s = 0.f;
+        if ((cols & 3) == 0) {
+            for (int c = lane * 4; c < cols; c += 256) {
+                const float4 a = ldg4(wr + c);
+                if (v) {
+                    const float4 b = ldg4(v + c);
+                    s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+                } else {
+                    s += a.x + a.y + a.z + a.w;
+                }
+            }
+        } else {
+            for (int c = lane; c < cols; c += 64) s += v ? wr[c] * v[c] : wr[c];
+        }
+        s = wave_sum(s);
+        if (lane == 0) out[r] = s;
+    }
 }
 
 // uraw[c] += sum_{r in chunk} vraw[r] * W[r][c]
@@ -874,6 +912,15 @@ int bg_axpby(const float* x, float a, float* y, float b, int64_t n, void* stream
     return BG_OK;
 }
 
+int bg_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
+    BG_REQUIRE(a && b && y && n > 0, "bg_add: bad argument");
+    BG_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && ((uintptr_t)y & 15) == 0,
+               "bg_add: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, as_stream(stream), a, b, y, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
 int bg_scale_add(const float* o, const float* gamma_dev, const float* x, float* y, int64_t n, void* stream) {
     BG_REQUIRE(o && gamma_dev && x && y && n > 0, "bg_scale_add: bad argument");
     BG_REQUIRE(((uintptr_t)o & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0,
@@ -911,6 +958,16 @@ int bg_tanh_fwd(const float* x, float* y, int64_t n, void* stream) {
 int bg_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream) {
     BG_REQUIRE(y && dy && dx && n > 0, "bg_tanh_bwd: bad argument");
     hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, as_stream(stream), y, dy, dx, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_gemv_rows(const float* w, const float* v, float* out, int rows, int cols, void* stream) {
+    BG_REQUIRE(w && out && rows > 0 && cols > 0, "bg_gemv_rows: bad argument");
+    BG_REQUIRE(((uintptr_t)w & 15) == 0 && ((uintptr_t)v & 15) == 0, "bg_gemv_rows: pointers must be 16-byte aligned");
+    int grid = (rows + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3(grid), dim3(EW_BLOCK), 0, as_stream(stream), w, v, out, rows, cols);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

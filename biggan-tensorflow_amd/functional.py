@@ -82,8 +82,12 @@ class Conv2dFn(Function):
         d = hip.conv_desc(N, H, W_, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode)
         y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         L = lib()
-        ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, d, x.device)
-        check(L.bg_conv2d_fwd(d, f32(x), f32(w), f32(bias), None, f32(y), 0, f32(ws), nb, stream()))
+        ctx.rgb = bool(L.bg_rgbconv_supported(d))      # <= 3 output channels: direct HBM-bound kernels
+        if ctx.rgb:
+            check(L.bg_rgbconv_fwd(d, f32(x), f32(w), f32(bias), f32(y), 0, stream()))
+        else:
+            ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, d, x.device)
+            check(L.bg_conv2d_fwd(d, f32(x), f32(w), f32(bias), None, f32(y), 0, f32(ws), nb, stream()))
         ctx.desc = d
         ctx.x, ctx.w, ctx.bias = x, w, bias
         return y
@@ -96,10 +100,18 @@ class Conv2dFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            ws, nb = hip.scratch(L.bg_conv2d_dgrad_workspace_bytes, d, x.device)
-            check(L.bg_conv2d_dgrad(d, f32(dy), f32(w), None, f32(dx), 0, f32(ws), nb, stream()))
+            if ctx.rgb:
+                check(L.bg_rgbconv_dgrad(d, f32(dy), f32(w), f32(dx), 0, stream()))
+            else:
+                ws, nb = hip.scratch(L.bg_conv2d_dgrad_workspace_bytes, d, x.device)
+                check(L.bg_conv2d_dgrad(d, f32(dy), f32(w), None, f32(dx), 0, f32(ws), nb, stream()))
 
         def wg(out):
+            if ctx.rgb:
+                nb = L.bg_rgbconv_wgrad_workspace_bytes(d)
+                ws = workspace(nb, x.device)
+                check(L.bg_rgbconv_wgrad(d, f32(x), f32(dy), f32(out), f32(ws), nb, stream()))
+                return
             nb = L.bg_conv2d_wgrad_workspace_bytes(d)
             ws = workspace(nb, x.device)
             check(L.bg_conv2d_wgrad(d, f32(x), f32(dy), f32(out), f32(ws), nb, stream()))
@@ -490,13 +502,36 @@ class AddFn(Function):
     @staticmethod
     def forward(ctx, a, b):
         a, b = _c(a), _c(b)
-        y = a.clone()
-        axpby(b, 1.0, y, 1.0)
+        y = torch.empty_like(a)
+        check(lib().bg_add(f32(a), f32(b), f32(y), a.numel(), stream()))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         return dy, dy
+
+
+class ForkFn(Function):
+    """Identity with two outputs for a tensor consumed by two branches (block input -> main path and
+    skip path, ops.py:253/263): the two incoming gradients are summed by a HIP kernel instead of the
+    autograd engine's own accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.detach().view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [_c(g) for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        out = torch.empty_like(gs[0])
+        check(lib().bg_add(f32(gs[0]), f32(gs[1]), f32(out), out.numel(), stream()))
+        for g in gs[2:]:
+            axpby(g, 1.0, out, 1.0)
+        return out, None
 
 
 class ScaleAddFn(Function):
@@ -634,6 +669,30 @@ class OrthoCosineRegFn(Function):
         rows = w.numel() // c
         W2 = w.view(rows, c)
         dev = w.device
+        ctx.lowrank = 2 * rows <= c
+        if ctx.lowrank:
+            # wide kernel: O(rows^2 c) form, the c x c Gram matrix is never materialised
+            L = lib()
+            G = torch.empty((rows, rows), dtype=torch.float32, device=dev)
+            gemm(W2, W2, G, rows, rows, c, c, c, rows, transB=True)                     # G = W W^T
+            s = torch.empty(rows, dtype=torch.float32, device=dev)
+            check(L.bg_gemv_rows(f32(W2), None, f32(s), rows, c, stream()))              # s = W 1
+            P = torch.empty((rows, c), dtype=torch.float32, device=dev)
+            gemm(G, W2, P, rows, c, rows, rows, c, c)                                    # P = G W
+            ab = torch.empty(2 * c, dtype=torch.float32, device=dev)
+            Wb = torch.empty((rows, c), dtype=torch.float32, device=dev)
+            loss = torch.zeros(1, dtype=torch.float32, device=dev)
+            check(L.bg_ortho_lowrank_cols(f32(W2), f32(P), f32(s), float(scale), f32(ab), f32(Wb), f32(loss),
+                                          rows, c, stream()))
+            Wa = torch.empty(rows, dtype=torch.float32, device=dev)
+            check(L.bg_gemv_rows(f32(W2), f32(ab), f32(Wa), rows, c, stream()))          # W alpha
+            H = torch.empty((rows, rows), dtype=torch.float32, device=dev)
+            gemm(Wb, W2, H, rows, rows, c, c, c, rows, transB=True)                      # H = W diag(beta) W^T
+            dW = torch.empty((rows, c), dtype=torch.float32, device=dev)
+            gemm(H, W2, dW, rows, c, rows, rows, c, c)                                   # H W
+            check(L.bg_ortho_lowrank_finish(f32(dW), f32(P), f32(s), f32(Wa), f32(ab), rows, c, stream()))
+            ctx.w, ctx.dW = w, dW
+            return loss
         A = torch.empty((c, c), dtype=torch.float32, device=dev)
         gemm(W2, W2, A, c, c, rows, c, c, c, transA=True)               # A = W^T W
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -645,6 +704,14 @@ class OrthoCosineRegFn(Function):
     @staticmethod
     def backward(ctx, g):
         g = _c(g)
+        if ctx.lowrank:
+            w, dWs = ctx.w, ctx.dW
+
+            def prod_lr(out):
+                check(lib().bg_scale_dev(f32(dWs), f32(g), f32(out), dWs.numel(), stream()))
+            dw = param_grad(w, ctx.needs_input_grad[0], prod_lr)
+            ctx.w = ctx.dW = None
+            return dw, None
         w, dA = ctx.w, ctx.dA
         c = w.shape[-1]
         rows = w.numel() // c

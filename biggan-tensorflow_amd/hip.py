@@ -49,6 +49,11 @@ SIGNATURES = {
     "bg_deconv2d_dgrad": (c_int, [_CD, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "bg_deconv2d_wgrad_workspace_bytes": (c_size_t, [_CD]),
     "bg_deconv2d_wgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
+    "bg_rgbconv_supported": (c_int, [_CD]),
+    "bg_rgbconv_fwd": (c_int, [_CD, _P, _P, _P, _P, c_int, _P]),
+    "bg_rgbconv_dgrad": (c_int, [_CD, _P, _P, _P, c_int, _P]),
+    "bg_rgbconv_wgrad_workspace_bytes": (c_size_t, [_CD]),
+    "bg_rgbconv_wgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
     "bg_gemm_workspace_bytes": (c_size_t, [_GD]),
     "bg_gemm": (c_int, [_GD, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "bg_spectral_norm_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -69,6 +74,7 @@ SIGNATURES = {
     "bg_sum_pool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "bg_sum_pool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "bg_axpby": (c_int, [_P, c_float, _P, c_float, c_int64, _P]),
+    "bg_add": (c_int, [_P, _P, _P, c_int64, _P]),
     "bg_scale_add": (c_int, [_P, _P, _P, _P, c_int64, _P]),
     "bg_dot": (c_int, [_P, _P, _P, c_int64, _P]),
     "bg_scale_dev": (c_int, [_P, _P, _P, c_int64, _P]),
@@ -82,6 +88,9 @@ SIGNATURES = {
     "bg_hinge_g_sums": (c_int, [_P, _P, c_int, _P]),
     "bg_hinge_g_grad": (c_int, [_P, c_double, c_float, _P, _P, c_int, _P]),
     "bg_ortho_cosine_fwd_bwd": (c_int, [_P, c_float, _P, _P, c_int, _P]),
+    "bg_gemv_rows": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "bg_ortho_lowrank_cols": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P]),
+    "bg_ortho_lowrank_finish": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     "bg_adam_tf_ema_step": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_float,
                                     c_int64, _P]),
     "bg_prof_enable": (None, [c_int]),

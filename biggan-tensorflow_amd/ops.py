@@ -198,11 +198,19 @@ def _add(a, b):
     return Fn.AddFn.apply(a, b)
 
 
+def _fork(x, n=2):
+    """A tensor consumed by n branches: the branch gradients are summed by a HIP kernel."""
+    if _is_meta(x) or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return Fn.ForkFn.apply(x, n)
+
+
 def resblock(x_init, channels, opt, use_bias=True, scope='resblock'):
     """ops.py:187-198."""
     with variable_scope(scope):
+        x_main, x_skip = _fork(x_init)
         with variable_scope('res1'):
-            x = conv(x_init, channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
+            x = conv(x_main, channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
             if opt["bn_in_d"]:
                 x = bn(x, opt=opt)
             x = opt["act"](x)
@@ -210,7 +218,7 @@ def resblock(x_init, channels, opt, use_bias=True, scope='resblock'):
             x = conv(x, channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
             if opt["bn_in_d"]:
                 x = bn(x, opt=opt)
-        return _add(x, x_init)
+        return _add(x, x_skip)
 
 
 def upconv(x, channels, opt, use_bias=True, _accumulate_into=None):
@@ -248,13 +256,14 @@ def g_conv(x, channels, opt, use_bias=True, _accumulate_into=None):
 def resblock_up(x_init, channels, opt, use_bias=True, scope='resblock_up'):
     """ops.py:232-248."""
     with variable_scope(scope):
+        x_main, x_skip = _fork(x_init)
         with variable_scope('res1'):
-            x = _bn_act(x_init, None, opt)
+            x = _bn_act(x_main, None, opt)
             x = upconv(x, channels, use_bias=use_bias, opt=opt)
         with variable_scope('res2'):
             x = _bn_act(x, None, opt)
         with variable_scope('skip'):
-            skip = upconv(x_init, channels, use_bias=use_bias, opt=opt)
+            skip = upconv(x_skip, channels, use_bias=use_bias, opt=opt)
         with variable_scope('res2'):
             x = g_conv(x, channels, use_bias=use_bias, opt=opt, _accumulate_into=skip)
     return x
@@ -264,13 +273,14 @@ def resblock_up_condition(x_init, z, channels, opt, use_bias=True, scope='resblo
     """ops.py:250-266.  The skip branch is evaluated before the last main-branch deconv so the
     residual sum is fused into that kernel's epilogue (same values, one pass less)."""
     with variable_scope(scope):
+        x_main, x_skip = _fork(x_init)
         with variable_scope('res1'):
-            x = _bn_act(x_init, z, opt)
+            x = _bn_act(x_main, z, opt)
             x = upconv(x, channels, use_bias=use_bias, opt=opt)
         with variable_scope('res2'):
             x = _bn_act(x, z, opt)
         with variable_scope('skip'):
-            skip = upconv(x_init, channels, use_bias=use_bias, opt=opt)
+            skip = upconv(x_skip, channels, use_bias=use_bias, opt=opt)
         with variable_scope('res2'):
             x = g_conv(x, channels, use_bias=use_bias, opt=opt, _accumulate_into=skip)
     return x
@@ -291,11 +301,12 @@ def downconv(x, channels, opt, use_bias=True, method=None):
 def resblock_down(x_init, channels, opt, use_bias=True, scope='resblock_down'):
     """ops.py:293-313."""
     with variable_scope(scope):
+        x_main, x_init = _fork(x_init)
         with variable_scope('res1'):
             if opt["bn_in_d"]:
-                x = bn(x_init, opt=opt)
+                x = bn(x_main, opt=opt)
             else:
-                x = x_init
+                x = x_main
             x = opt["act"](x)
             res_method = opt["downsampling_method"]
             if res_method != 'strided_conv3':
@@ -335,10 +346,11 @@ def self_attention_2(x, channels, opt, scope='self_attention'):
     """ops.py:467-492."""
     with variable_scope(scope):
         use_bias = opt.get("self_attention_bias", False)
-        f = conv(x, channels // 8, kernel=1, stride=1, opt=opt, scope='f_conv', use_bias=use_bias)
+        x_f, x_g, x_h, x = _fork(x, 4)
+        f = conv(x_f, channels // 8, kernel=1, stride=1, opt=opt, scope='f_conv', use_bias=use_bias)
         f = max_pooling(f)
-        g = conv(x, channels // 8, kernel=1, stride=1, opt=opt, scope='g_conv', use_bias=use_bias)
-        h = conv(x, channels // 2, kernel=1, stride=1, opt=opt, scope='h_conv', use_bias=use_bias)
+        g = conv(x_g, channels // 8, kernel=1, stride=1, opt=opt, scope='g_conv', use_bias=use_bias)
+        h = conv(x_h, channels // 2, kernel=1, stride=1, opt=opt, scope='h_conv', use_bias=use_bias)
         h = max_pooling(h)
         gamma = get_variable("gamma", [1], initializer=S.constant_initializer(0.0))
         if _is_meta(x):

@@ -80,6 +80,17 @@ size_t bg_deconv2d_wgrad_workspace_bytes(const BgConvDesc*);
 int bg_deconv2d_wgrad(const BgConvDesc*, const float* x, const float* dy, float* dw,
                       void* ws, size_t ws_bytes, void* stream);
 
+/* Direct (vector-ALU, HBM-bound) path for k x k stride-1 convolutions with <= 3 output channels:
+ * the generator's RGB head G_logit (BigGAN.py:570 -> ops.py:49-113).  Same arithmetic as
+ * bg_conv2d_*; bg_rgbconv_supported tells whether a geometry qualifies. */
+int bg_rgbconv_supported(const BgConvDesc*);
+int bg_rgbconv_fwd  (const BgConvDesc*, const float* x, const float* w, const float* bias, float* y,
+                     int accumulate, void* stream);
+int bg_rgbconv_dgrad(const BgConvDesc*, const float* dy, const float* w, float* dx, int accumulate, void* stream);
+size_t bg_rgbconv_wgrad_workspace_bytes(const BgConvDesc*);
+int bg_rgbconv_wgrad(const BgConvDesc*, const float* x, const float* dy, float* dw,
+                     void* ws, size_t ws_bytes, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Plain (batched) matrix products: tf.matmul call sites ops.py:163-165 (dense), 481,485
  * (attention), utils.py:198,222 (Gram matrix of the regulariser).
@@ -164,6 +175,7 @@ int bg_sum_pool_bwd(const float* dy, float* dx, int N, int HW, int C, void* stre
 
 /* y = a*x + b*y elementwise family used by residual adds, gamma*o + x (ops.py:490), tanh (ops.py:539) */
 int bg_axpby(const float* x, float a, float* y, float b, int64_t n, void* stream);
+int bg_add(const float* a, const float* b, float* y, int64_t n, void* stream);            /* y = a + b */
 int bg_scale_add(const float* o, const float* gamma_dev, const float* x, float* y, int64_t n, void* stream);
 int bg_dot(const float* a, const float* b, float* out_accum, int64_t n, void* stream);   /* out += <a,b> */
 int bg_scale_dev(const float* x, const float* s_dev, float* y, int64_t n, void* stream);  /* y = s*x, s a device scalar */
@@ -205,6 +217,16 @@ int bg_hinge_g_grad(const float* sums, double n_global, float flood, float* d_fa
  *   fwd: loss_accum[0] += scale/2 * sum R^2 ; bwd: dA (so that dW = W (dA + dA^T), via bg_gemm).
  * ------------------------------------------------------------------------------------------ */
 int bg_ortho_cosine_fwd_bwd(const float* A, float scale, float* loss_accum, float* dA, int c, void* stream);
+/* Low-rank form of the same function for wide kernels W[rows, c] with rows < c (first/dense2 is
+ * [184, 16*16*ch]): with G = W W^T, s = W 1, P = G W (bg_gemm) the c x c Gram matrix is never formed.
+ *   cols:   alpha_beta[0:c] = alpha, [c:2c] = beta, Wb = W diag(beta), loss_accum[0] += loss
+ *   finish: dW = 2*dW_in + s alpha^T + (W alpha) 1^T + 2 P diag(beta), dW_in = (Wb W^T) W */
+/* out[r] = sum_c W[r,c] * v[c] (v == NULL: row sums) - the s = W 1 and W alpha vectors of the low-rank form */
+int bg_gemv_rows(const float* w, const float* v, float* out, int rows, int cols, void* stream);
+int bg_ortho_lowrank_cols(const float* W, const float* P, const float* s, float scale, float* alpha_beta,
+                          float* Wb, float* loss_accum, int rows, int c, void* stream);
+int bg_ortho_lowrank_finish(float* dW, const float* P, const float* s, const float* Walpha,
+                            const float* alpha_beta, int rows, int c, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * TF AdamOptimizer (+ MovingAverageOptimizer shadow) over a flat parameter arena (BigGAN.py:923-927):

@@ -55,6 +55,11 @@ CONV_CASES = [
     (1, 4, 32, 32, 3, 1, 1, True),      # 4x4 map: every pixel touches the reflect border
     (5, 12, 20, 72, 3, 2, 1, True),     # ragged tiles in M, N and K
     (2, 32, 64, 128, 3, 1, 1, False),   # 128x128 tile path
+    (2, 16, 64, 3, 3, 1, 1, True),      # RGB head (direct kernels), with bias
+    (1, 8, 96, 3, 3, 1, 1, False),      # RGB head at ch=96: channel chunks of 64 + 32
+    (3, 4, 32, 1, 3, 1, 1, False),      # single output channel, 4x4 map (all-border reflect)
+    (2, 64, 16, 2, 1, 1, 0, False),     # 1x1, two output channels
+    (64, 4, 1024, 1024, 3, 1, 1, False),  # small output, long K: split-K slabs
 ]
 
 
@@ -71,7 +76,7 @@ def test_conv2d_fwd_bwd(N, H, Cin, Cout, k, s, pad, use_bias):
     xin = xt.permute(0, 3, 1, 2)
     if pad:
         xin = F.pad(xin, (pad, pad, pad, pad), mode="reflect")
-    yr = F.conv2d(xin, wt.permute(3, 2, 0, 1), stride=s).permute(0, 2, 3, 1)
+    yr = F.conv2d(xin.contiguous(), wt.permute(3, 2, 0, 1).contiguous(), stride=s).permute(0, 2, 3, 1)
     bt = None
     if use_bias:
         bt = torch.tensor(b, requires_grad=True)
@@ -436,7 +441,8 @@ def test_hinge_losses_with_flood(scale):
     assert rel_err(t2n(fc2.grad), ft2.grad.numpy()) < 1e-6     # includes the flood sign flip
 
 
-@pytest.mark.parametrize("shape", [(3, 3, 8, 16), (96, 184), (4, 4, 32, 8), (3, 3, 8, 3), (32, 320)])
+@pytest.mark.parametrize("shape", [(3, 3, 8, 16), (96, 184), (4, 4, 32, 8), (3, 3, 8, 3), (32, 320), (184, 1024),
+                                   (7, 33)])
 def test_ortho_cosine_regulariser(shape):
     Fn = _fn()
     rng = np.random.default_rng(sum(shape))
