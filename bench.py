@@ -148,7 +148,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % torch.cuda.device_count())   # (ranks share a card only in gloo rehearsals)
 
     img, ch, B, desc = WORKLOADS[a.workload]
     if a.batch:

@@ -1,0 +1,113 @@
+"""Data-parallel correctness on the GPU: two ranks (both on cuda:0, process group "gloo" - the only
+backend two processes can share one card with; the 8-GPU run uses "nccl" = RCCL with the same code)
+each take half of the global batch and must reproduce the single-process full-batch losses and
+gradients: cross-replica batch-norm statistics, globally averaged hinge loss (flood sign), SUM
+all-reduce of the flat gradient arenas, 1/world weighting of the replicated regulariser."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+IMG, CH, ZD, B = 64, 8, 64, 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _slice_draws(d, lo, hi):
+    return {k: v[lo:hi] for k, v in d.items()}
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch.distributed as dist
+    from biggan_tensorflow_amd import parallel
+    from oracle import ref_model as RM
+    from tests.common import oracle_trainer, hip_model_like, dev_draws, t2n
+    torch.cuda.set_device(0)
+    parallel.init_from_env(backend="gloo")
+    tr = oracle_trainer(IMG, CH, ZD, B)              # same seed on both ranks: identical replicas
+    gan = hip_model_like(tr)
+    assert gan.world == world and gan.rank == rank
+    batch = RM.synthetic_batch(tr.cfg, 5, B)
+    lo, hi = parallel.shard_batch(B, rank, world)
+
+    def cu(a):
+        return torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda")
+    out = {}
+    d = gan.d_step(cu(batch["real"][lo:hi]), cu(batch["z_d"][lo:hi]), dev_draws(_slice_draws(batch["aug_real"], lo, hi)),
+                   dev_draws(_slice_draws(batch["aug_fake_d"], lo, hi)), apply=False)
+    out["d_loss"] = d["d_loss"].item()
+    out["d_grads"] = t2n(gan.d_arena.grads).copy()
+    hip0 = {k: v for k, v in tr.vs.export().items()}
+    gan.store.load_arrays({k: v.astype(np.float32) for k, v in hip0.items()}, reset_ema=False)
+    g = gan.g_step(hi - lo, cu(batch["z_g"][lo:hi]), dev_draws(_slice_draws(batch["aug_fake_g"], lo, hi)), apply=False)
+    out["g_adv"] = g["g_adv"].item()
+    out["g_grads"] = t2n(gan.g_arena.grads).copy()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single():
+    from oracle import ref_model as RM
+    from tests.common import oracle_trainer, hip_model_like, dev_draws, t2n
+    tr = oracle_trainer(IMG, CH, ZD, B)
+    gan = hip_model_like(tr)
+    batch = RM.synthetic_batch(tr.cfg, 5, B)
+
+    def cu(a):
+        return torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda")
+    out = {}
+    d = gan.d_step(cu(batch["real"]), cu(batch["z_d"]), dev_draws(batch["aug_real"]), dev_draws(batch["aug_fake_d"]),
+                   apply=False)
+    out["d_loss"] = d["d_loss"].item()
+    out["d_grads"] = t2n(gan.d_arena.grads).copy()
+    gan.store.load_arrays({k: v.astype(np.float32) for k, v in tr.vs.export().items()}, reset_ema=False)
+    g = gan.g_step(B, cu(batch["z_g"]), dev_draws(batch["aug_fake_g"]), apply=False)
+    out["g_adv"] = g["g_adv"].item()
+    out["g_grads"] = t2n(gan.g_arena.grads).copy()
+    return out
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+
+def test_two_rank_data_parallel_matches_single_process():
+    ref = _single()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(world):
+        o = res[r]
+        assert abs(o["d_loss"] - ref["d_loss"]) <= 1e-5 * abs(ref["d_loss"]), (r, o["d_loss"], ref["d_loss"])
+        assert abs(o["g_adv"] - ref["g_adv"]) <= 1e-5 * abs(ref["g_adv"]), (r, o["g_adv"], ref["g_adv"])
+        # flat arenas after the SUM all-reduce: equal on both ranks and equal to the single-process gradient
+        assert _rel(o["d_grads"], ref["d_grads"]) < 1e-4, (r, _rel(o["d_grads"], ref["d_grads"]))
+        assert _rel(o["g_grads"], ref["g_grads"]) < 1e-4, (r, _rel(o["g_grads"], ref["g_grads"]))
+    assert np.array_equal(res[0]["d_grads"], res[1]["d_grads"])
+    assert np.array_equal(res[0]["g_grads"], res[1]["g_grads"])
