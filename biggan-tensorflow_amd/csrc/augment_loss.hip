@@ -33,7 +33,7 @@ __device__ __forceinline__ void da_color_pre(float (&v)[DA_MAXC], int C, float u
 }
 
 // per-sample sum of the brightness/saturation-adjusted image (reduce_mean of rand_contrast, :35)
-__global__ __launch_bounds__(AL_BLOCK) void da_mean_kernel(const float* __restrict__ x, DaArgs a, float* sums) {
+__global__ __launch_bounds__(AL_BLOCK) void da_mean_kernel(const float* __restrict__ x, DaArgs a, double* sums) {
     __shared__ float sh[4];
     const int n = blockIdx.y;
     const int64_t px = (int64_t)a.S * a.S;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(AL_BLOCK) void da_mean_kernel(const float* __restri
             if (c < a.C) s += v[c];
     }
     s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) atomicAdd(&sums[n], s);
+    if (threadIdx.x == 0) atomicAdd(&sums[n], (double)s);     // fp64: order-independent to ~1e-16
 }
 
 __device__ __forceinline__ bool da_cut(const DaArgs& a, int n, int i, int j) {
@@ -62,7 +62,7 @@ __device__ __forceinline__ bool da_cut(const DaArgs& a, int n, int i, int j) {
 }
 
 __global__ __launch_bounds__(AL_BLOCK) void da_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, DaArgs a,
-                                                           const float* sums) {
+                                                           const double* sums) {
     const int64_t px = (int64_t)a.S * a.S;
     const int64_t total = (int64_t)a.N * px;
     const bool color = a.policy & 1, trans = a.policy & 2, cut = a.policy & 4;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(AL_BLOCK) void da_fwd_kernel(const float* __restric
             for (int c = 0; c < DA_MAXC; ++c) v[c] = c < a.C ? p[c] : 0.f;
             if (color) {
                 da_color_pre(v, a.C, a.u_b[n], a.u_s[n]);
-                const float m = sums[n] / (float)(px * a.C);          // rand_contrast :33-37
+                const float m = (float)(sums[n] / (double)(px * a.C));   // rand_contrast :33-37
                 const float mag = a.u_c[n] + 0.5f;
 #pragma unroll
                 for (int c = 0; c < DA_MAXC; ++c)
@@ -113,7 +113,7 @@ __device__ __forceinline__ bool da_bwd_src(const DaArgs& a, int n, int p, int q,
     return true;
 }
 
-__global__ __launch_bounds__(AL_BLOCK) void da_bwd_sum_kernel(const float* __restrict__ dy, DaArgs a, float* sums) {
+__global__ __launch_bounds__(AL_BLOCK) void da_bwd_sum_kernel(const float* __restrict__ dy, DaArgs a, double* sums) {
     __shared__ float sh[4];
     const int n = blockIdx.y;
     const int64_t px = (int64_t)a.S * a.S;
@@ -128,11 +128,11 @@ __global__ __launch_bounds__(AL_BLOCK) void da_bwd_sum_kernel(const float* __res
         }
     }
     s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) atomicAdd(&sums[n], s);
+    if (threadIdx.x == 0) atomicAdd(&sums[n], (double)s);
 }
 
 __global__ __launch_bounds__(AL_BLOCK) void da_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, DaArgs a,
-                                                           const float* sums) {
+                                                           const double* sums) {
     const int64_t px = (int64_t)a.S * a.S;
     const int64_t total = (int64_t)a.N * px;
     const bool color = a.policy & 1;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(AL_BLOCK) void da_bwd_kernel(const float* __restric
         if (color) {
             // contrast: x3 = (x2 - m) c + m, m = mean_hwc(x2)  ->  dx2 = c dx3 + (1-c) mean_hwc(dx3)
             const float cm = a.u_c[n] + 0.5f;
-            const float mg = sums[n] / (float)(px * a.C);
+            const float mg = (float)(sums[n] / (double)(px * a.C));
             float mc = 0.f;
 #pragma unroll
             for (int c = 0; c < DA_MAXC; ++c)
@@ -347,7 +347,7 @@ extern "C" {
 
 int bg_diffaugment_fwd(const float* x, float* y, const float* u_b, const float* u_s, const float* u_c,
                        const int32_t* t_x, const int32_t* t_y, const int32_t* o_x, const int32_t* o_y, int N, int S,
-                       int C, int policy, float* mean_ws, void* stream) {
+                       int C, int policy, double* mean_ws, void* stream) {
     int rc = da_check(x, y, N, S, C, policy);
     if (rc) return rc;
     BG_REQUIRE(!(policy & 1) || (u_b && u_s && u_c && mean_ws), "bg_diffaugment_fwd: color needs u_b,u_s,u_c,mean_ws");
@@ -357,7 +357,7 @@ int bg_diffaugment_fwd(const float* x, float* y, const float* u_b, const float* 
     DaArgs a{u_b, u_s, u_c, t_x, t_y, o_x, o_y, N, S, C, policy};
     const int64_t px = (int64_t)S * S;
     if (policy & 1) {
-        if (hipMemsetAsync(mean_ws, 0, sizeof(float) * N, s) != hipSuccess) {
+        if (hipMemsetAsync(mean_ws, 0, sizeof(double) * N, s) != hipSuccess) {
             set_error("bg_diffaugment_fwd: memset failed");
             return BG_ERR_LAUNCH;
         }
@@ -375,7 +375,7 @@ int bg_diffaugment_fwd(const float* x, float* y, const float* u_b, const float* 
 
 int bg_diffaugment_bwd(const float* dy, float* dx, const float* u_s, const float* u_c, const int32_t* t_x,
                        const int32_t* t_y, const int32_t* o_x, const int32_t* o_y, int N, int S, int C, int policy,
-                       float* mean_ws, void* stream) {
+                       double* mean_ws, void* stream) {
     int rc = da_check(dy, dx, N, S, C, policy);
     if (rc) return rc;
     BG_REQUIRE(!(policy & 1) || (u_s && u_c && mean_ws), "bg_diffaugment_bwd: color needs u_s,u_c,mean_ws");
@@ -385,7 +385,7 @@ int bg_diffaugment_bwd(const float* dy, float* dx, const float* u_s, const float
     DaArgs a{nullptr, u_s, u_c, t_x, t_y, o_x, o_y, N, S, C, policy};
     const int64_t px = (int64_t)S * S;
     if (policy & 1) {
-        if (hipMemsetAsync(mean_ws, 0, sizeof(float) * N, s) != hipSuccess) {
+        if (hipMemsetAsync(mean_ws, 0, sizeof(double) * N, s) != hipSuccess) {
             set_error("bg_diffaugment_bwd: memset failed");
             return BG_ERR_LAUNCH;
         }

@@ -25,8 +25,8 @@ __device__ __forceinline__ void stg4(float* p, const float4& v) { *reinterpret_c
 // over rows, combined across the block's row-lanes through LDS and added to out[q*qstride + seg*C + c]
 // with one float atomic per column per block.
 // ==========================================================================================
-template <int NQ, int VEC, class Fn>
-__global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(Fn fn, float* out, int64_t qstride,
+template <int NQ, int VEC, class Fn, class OutT>
+__global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(Fn fn, OutT* out, int64_t qstride,
                                                              int64_t rows_per_seg, int C, int rows_per_block) {
     __shared__ float red[NQ * EW_BLOCK * VEC];   // VEC*NQ floats per thread
     const int CV = C / VEC;                      // vector columns
@@ -60,15 +60,15 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(Fn fn, float* out, 
                 for (int j = 0; j < VEC; ++j) {
                     float s = 0.f;
                     for (int l = 0; l < lanes; ++l) s += red[(q * VEC + j) * EW_BLOCK + l * tx + cq];
-                    atomicAdd(&out[q * qstride + (int64_t)seg * C + cv * VEC + j], s);
+                    atomicAdd(&out[q * qstride + (int64_t)seg * C + cv * VEC + j], (OutT)s);
                 }
         }
         __syncthreads();
     }
 }
 
-template <int NQ, class Fn>
-static void launch_colreduce(Fn fn, float* out, int64_t qstride, int64_t rows_per_seg, int nseg, int C,
+template <int NQ, class Fn, class OutT>
+static void launch_colreduce(Fn fn, OutT* out, int64_t qstride, int64_t rows_per_seg, int nseg, int C,
                              hipStream_t s) {
     // ~1024 blocks in total, at least 32 rows per block
     int64_t blocks_per_seg = (1024 + nseg - 1) / nseg;
@@ -77,10 +77,10 @@ static void launch_colreduce(Fn fn, float* out, int64_t qstride, int64_t rows_pe
     blocks_per_seg = (rows_per_seg + rpb - 1) / rpb;
     dim3 grid((unsigned)blocks_per_seg, (unsigned)nseg);
     if (C % 4 == 0)
-        hipLaunchKernelGGL((colreduce_kernel<NQ, 4, Fn>), grid, dim3(EW_BLOCK), 0, s, fn, out, qstride, rows_per_seg,
+        hipLaunchKernelGGL((colreduce_kernel<NQ, 4, Fn, OutT>), grid, dim3(EW_BLOCK), 0, s, fn, out, qstride, rows_per_seg,
                            C, (int)rpb);
     else
-        hipLaunchKernelGGL((colreduce_kernel<NQ, 1, Fn>), grid, dim3(EW_BLOCK), 0, s, fn, out, qstride, rows_per_seg,
+        hipLaunchKernelGGL((colreduce_kernel<NQ, 1, Fn, OutT>), grid, dim3(EW_BLOCK), 0, s, fn, out, qstride, rows_per_seg,
                            C, (int)rpb);
 }
 
@@ -116,12 +116,12 @@ struct BnStatsFn {
     }
 };
 
-__global__ void bn_finalize_kernel(const float* sums, double count, float eps, float momentum, int unbiased,
+__global__ void bn_finalize_kernel(const double* sums, double count, float eps, float momentum, int unbiased,
                                    float* mean, float* rstd, float* mm, float* mv, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double m = (double)sums[c] / count;
-    double var = (double)sums[C + c] / count - m * m;
+    const double m = sums[c] / count;
+    double var = sums[C + c] / count - m * m;
     if (var < 0) var = 0;
     mean[c] = (float)m;
     rstd[c] = rsqrtf((float)var + eps);
@@ -580,11 +580,11 @@ __global__ __launch_bounds__(EW_BLOCK) void tanh_bwd_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(EW_BLOCK) void sn_rowdot_kernel(const float* __restrict__ w,
                                                               const float* __restrict__ u, float* __restrict__ vraw,
-                                                              float* ssv, int rows, int cols) {
+                                                              double* ssv, int rows, int cols) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
-    float ss = 0.f;
+    double ss = 0.0;
     for (int r = wave; r < rows; r += nwaves) {
         const float* wr = w + (int64_t)r * cols;
         float s = 0.f;
@@ -599,10 +599,12 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_rowdot_kernel(const float* __rest
         s = wave_sum(s);
         if (lane == 0) {
             vraw[r] = s;
-            ss += s * s;
+            ss += (double)s * (double)s;
         }
     }
-    if (lane == 0 && ss != 0.f) atomicAdd(ssv, ss);
+    // fp64 accumulation: the sum is the same to ~1e-16 whatever the arrival order of the waves, so
+    // the forward pass is reproducible from run to run
+    if (lane == 0 && ss != 0.0) atomicAdd(ssv, ss);
 }
 
 // out[r] = sum_c W[r][c] * v[c]   (one wave per row; v == nullptr: plain row sums)
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(EW_BLOCK) void gemv_rows_kernel(const float* __rest
 
 // uraw[c] += sum_{r in chunk} vraw[r] * W[r][c]
 __global__ __launch_bounds__(EW_BLOCK) void sn_colsum_kernel(const float* __restrict__ w,
-                                                              const float* __restrict__ vraw, float* uraw, int rows,
+                                                              const float* __restrict__ vraw, double* uraw, int rows,
                                                               int cols, int rows_per_block) {
     const int r0 = blockIdx.y * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
@@ -642,35 +644,35 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_colsum_kernel(const float* __rest
     if (c >= cols) return;
     float s = 0.f;
     for (int r = r0; r < r1; ++r) s += vraw[r] * w[(int64_t)r * cols + c];
-    atomicAdd(&uraw[c], s);
+    atomicAdd(&uraw[c], (double)s);
 }
 
-// single block: norms, u_out, sigma
-__global__ __launch_bounds__(EW_BLOCK) void sn_finalize_kernel(float* scr, const float* uraw, float* u_out,
+// single block: norms, u_out, sigma.  scr (doubles): [0] = sum v_^2, [1] = sigma, [2] = rs_v
+__global__ __launch_bounds__(EW_BLOCK) void sn_finalize_kernel(double* scr, const double* uraw, float* u_out,
                                                                 float* sigma_out, int cols) {
     __shared__ float sh[4];
-    const float rs_v = rsqrtf(fmaxf(scr[0], 1e-12f));       // l2_normalize(v_)
+    const float rs_v = rsqrtf(fmaxf((float)scr[0], 1e-12f));       // l2_normalize(v_)
     float ss = 0.f;
     for (int c = threadIdx.x; c < cols; c += EW_BLOCK) {
-        const float t = uraw[c] * rs_v;                     // u_ = v_hat W
+        const float t = (float)uraw[c] * rs_v;                     // u_ = v_hat W
         ss += t * t;
     }
     ss = block_sum_256(ss, sh);
-    const float rs_u = rsqrtf(fmaxf(ss, 1e-12f));           // l2_normalize(u_)
-    for (int c = threadIdx.x; c < cols; c += EW_BLOCK) u_out[c] = uraw[c] * rs_v * rs_u;
+    const float rs_u = rsqrtf(fmaxf(ss, 1e-12f));                  // l2_normalize(u_)
+    for (int c = threadIdx.x; c < cols; c += EW_BLOCK) u_out[c] = (float)uraw[c] * rs_v * rs_u;
     if (threadIdx.x == 0) {
-        const float sigma = ss * rs_u;                      // v_hat W u_hat^T = u_ . u_hat
+        const float sigma = ss * rs_u;                             // v_hat W u_hat^T = u_ . u_hat
         scr[1] = sigma;
         scr[2] = rs_v;
         *sigma_out = sigma;
     }
 }
 
-__global__ __launch_bounds__(EW_BLOCK) void sn_normalize_kernel(const float* __restrict__ w, const float* scr,
+__global__ __launch_bounds__(EW_BLOCK) void sn_normalize_kernel(const float* __restrict__ w, const double* scr,
                                                                  const float* vraw, float* __restrict__ wn,
                                                                  float* v_out, int64_t n, int rows) {
-    const float sigma = scr[1];
-    const float rs_v = scr[2];
+    const float sigma = (float)scr[1];
+    const float rs_v = (float)scr[2];
     const int64_t n4 = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
         float4 a = ldg4(w + i * 4);
@@ -720,7 +722,7 @@ using namespace bg;
 
 extern "C" {
 
-int bg_bn_stats(const float* x, float* sums, int64_t rows, int C, void* stream) {
+int bg_bn_stats(const float* x, double* sums, int64_t rows, int C, void* stream) {
     BG_REQUIRE(x && sums && rows > 0 && C > 0, "bg_bn_stats: bad argument");
     BnStatsFn fn{x, C};
     launch_colreduce<2>(fn, sums, (int64_t)C, rows, 1, C, as_stream(stream));
@@ -728,7 +730,7 @@ int bg_bn_stats(const float* x, float* sums, int64_t rows, int C, void* stream) 
     return BG_OK;
 }
 
-int bg_bn_finalize(const float* sums, double count, float eps, float momentum, int unbiased_moving_var, float* mean,
+int bg_bn_finalize(const double* sums, double count, float eps, float momentum, int unbiased_moving_var, float* mean,
                    float* rstd, float* moving_mean, float* moving_var, int C, void* stream) {
     BG_REQUIRE(sums && mean && rstd && C > 0 && count > 0, "bg_bn_finalize: bad argument");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count, eps,
@@ -974,7 +976,8 @@ int bg_gemv_rows(const float* w, const float* v, float* out, int rows, int cols,
 
 size_t bg_spectral_norm_workspace_bytes(int rows, int cols) {
     if (rows <= 0 || cols <= 0) return 0;
-    return sizeof(float) * (size_t)(4 + rows + cols);
+    // doubles: [4 + cols] (sum v^2, sigma, rs_v, pad, u accumulators) ; floats: [rows] (v_)
+    return sizeof(double) * (size_t)(4 + cols) + sizeof(float) * (size_t)rows;
 }
 
 int bg_spectral_norm_fwd(const float* w, const float* u_in, float* u_out, float* v_out, float* sigma_out,
@@ -982,12 +985,13 @@ int bg_spectral_norm_fwd(const float* w, const float* u_in, float* u_out, float*
     BG_REQUIRE(w && u_in && u_out && v_out && sigma_out && w_norm && rows > 0 && cols > 0,
                "bg_spectral_norm_fwd: bad argument");
     BG_REQUIRE(ws && ws_bytes >= bg_spectral_norm_workspace_bytes(rows, cols), "bg_spectral_norm_fwd: workspace too small");
-    BG_REQUIRE(((uintptr_t)w & 15) == 0 && ((uintptr_t)w_norm & 15) == 0 && ((uintptr_t)u_in & 15) == 0,
+    BG_REQUIRE(((uintptr_t)w & 15) == 0 && ((uintptr_t)w_norm & 15) == 0 && ((uintptr_t)u_in & 15) == 0 &&
+                   ((uintptr_t)ws & 15) == 0,
                "bg_spectral_norm_fwd: pointers must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
-    float* scr = reinterpret_cast<float*>(ws);
-    float* vraw = scr + 4;
-    float* uraw = vraw + rows;
+    double* scr = reinterpret_cast<double*>(ws);
+    double* uraw = scr + 4;
+    float* vraw = reinterpret_cast<float*>(uraw + cols);
     if (hipMemsetAsync(scr, 0, bg_spectral_norm_workspace_bytes(rows, cols), s) != hipSuccess) {
         set_error("bg_spectral_norm_fwd: memset failed");
         return BG_ERR_LAUNCH;

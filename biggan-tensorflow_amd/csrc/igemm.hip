@@ -175,7 +175,7 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ as, const flo
 // NN kernel
 // ------------------------------------------------------------------------------------------
 template <int TM, int TN, int WM, int WN, bool BT, int MODE, bool MIRROR, bool VEC>
-__global__ __launch_bounds__(256) void nn_kernel(const NNParams p) {
+__global__ __launch_bounds__(256, (TM * TN == 4 && !MIRROR) ? 4 : 1) void nn_kernel(const NNParams p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int LDA = BM + 2;                 // == 2 (mod 8): conflict-free transposing writes
     constexpr int LDB = BT ? BN + 2 : BN + 4;   // BT: transposing writes ; else 16-byte aligned rows
@@ -204,8 +204,9 @@ __global__ __launch_bounds__(256) void nn_kernel(const NNParams p) {
         Bbase += (int64_t)zo * p.strideB;
         Obase += (int64_t)zo * p.strideC;
     } else if (MODE == GATHER_TCONV) {
-        ph = zo / g.pstep;
-        pw = zo % g.pstep;
+        // heaviest phase first: for k3 s2 the odd phases have 2 taps per axis, the even ones 1
+        ph = g.pstep - 1 - zo / g.pstep;
+        pw = g.pstep - 1 - zo % g.pstep;
     }
 
     // tap enumeration of this phase
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256) void nn_slab_reduce_kernel(const float* __rest
 // TN kernel: out[(tap, ca)][cb] = sum_rows A(row, tap)[ca] * Bv(row)[cb]   (taps flattened into M)
 // ------------------------------------------------------------------------------------------
 template <int TM, int TN, int WM, int WN, int MODE, bool VEC>
-__global__ __launch_bounds__(256) void tn_kernel(const TNParams p) {
+__global__ __launch_bounds__(256, (TM * TN == 4) ? 4 : 1) void tn_kernel(const TNParams p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int ALOADS = (BKT * BM / 4 + 255) / 256;
@@ -473,6 +474,13 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNParams p) {
     float4 ra[ALOADS], rb[BLOADS];
     int l_row = row_begin;
 
+    // pixel position of each A-load row, advanced incrementally by BKT pixels per K tile (no divisions
+    // in the loop: the decode would otherwise cost as many VALU cycles as the tile's MFMAs)
+    RowPos apos[ALOADS];
+#pragma unroll
+    for (int i = 0; i < ALOADS; ++i)
+        apos[i] = decompose_row<MODE>(g, row_begin + (t + 256 * i) / (BM / 4), p.M, 0, 0);
+
     auto load_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < ALOADS; ++i) {
@@ -480,8 +488,21 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNParams p) {
             const int kr = idx / (BM / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int m = l_row + kr;
+            RowPos rp = apos[i];
+            rp.valid = m < p.M;
+            if (MODE == GATHER_PLAIN) {
+                apos[i].b += BKT;
+            } else {
+                apos[i].wo += BKT;
+                while (apos[i].wo >= g.Wq) {
+                    apos[i].wo -= g.Wq;
+                    if (++apos[i].ho == g.Hq) {
+                        apos[i].ho = 0;
+                        ++apos[i].b;
+                    }
+                }
+            }
             if (idx < BKT * BM / 4 && m < row_end) {
-                RowPos rp = decompose_row<MODE>(g, m, p.M, 0, 0);
                 if (VEC) {
                     if (a_c[i] >= 0) {
                         int64_t off[1];

@@ -335,18 +335,18 @@ class BnActFn(Function):
         rstd = torch.empty(C, dtype=torch.float32, device=dev)
         count = float(N * HW * world)
         if is_training:
-            sums = torch.zeros(2 * C, dtype=torch.float32, device=dev)
-            check(L.bg_bn_stats(f32(x), f32(sums), N * HW, C, stream()))
+            sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+            check(L.bg_bn_stats(f32(x), hip.ptr(sums), N * HW, C, stream()))
             if reduce_fn is not None:
                 reduce_fn(sums)
-            check(L.bg_bn_finalize(f32(sums), count, eps, momentum, int(unbiased_mv), f32(mean), f32(rstd),
+            check(L.bg_bn_finalize(hip.ptr(sums), count, eps, momentum, int(unbiased_mv), f32(mean), f32(rstd),
                                    f32(moving_mean), f32(moving_var), C, stream()))
         else:
             # inference: population statistics (ops.py:643)
-            sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+            sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
             sums[:C].copy_(moving_mean)
             sums[C:].copy_(moving_var + moving_mean * moving_mean)
-            check(L.bg_bn_finalize(f32(sums), 1.0, eps, 0.0, 0, f32(mean), f32(rstd), None, None, C, stream()))
+            check(L.bg_bn_finalize(hip.ptr(sums), 1.0, eps, 0.0, 0, f32(mean), f32(rstd), None, None, C, stream()))
         y = torch.empty_like(x)
         gamma_c, beta_c = _c(gamma), _c(beta)
         check(L.bg_bn_apply_act_fwd(f32(x), f32(mean), f32(rstd), f32(gamma_c), f32(beta_c), per_sample,
@@ -575,9 +575,9 @@ class DiffAugmentFn(Function):
         N, S, S2, C = x.shape
         assert S == S2
         y = torch.empty_like(x)
-        ws = torch.empty(N, dtype=torch.float32, device=x.device)
+        ws = torch.empty(N, dtype=torch.float64, device=x.device)
         check(lib().bg_diffaugment_fwd(f32(x), f32(y), f32(u_b), f32(u_s), f32(u_c), i32(t_x), i32(t_y), i32(o_x),
-                                       i32(o_y), N, S, C, policy_bits, f32(ws), stream()))
+                                       i32(o_y), N, S, C, policy_bits, hip.ptr(ws), stream()))
         ctx.draws = (u_s, u_c, t_x, t_y, o_x, o_y)
         ctx.policy = policy_bits
         ctx.shape = x.shape
@@ -589,9 +589,9 @@ class DiffAugmentFn(Function):
         u_s, u_c, t_x, t_y, o_x, o_y = ctx.draws
         N, S, _, C = ctx.shape
         dx = torch.empty_like(dy)
-        ws = torch.empty(N, dtype=torch.float32, device=dy.device)
+        ws = torch.empty(N, dtype=torch.float64, device=dy.device)
         check(lib().bg_diffaugment_bwd(f32(dy), f32(dx), f32(u_s), f32(u_c), i32(t_x), i32(t_y), i32(o_x), i32(o_y),
-                                       N, S, C, ctx.policy, f32(ws), stream()))
+                                       N, S, C, ctx.policy, hip.ptr(ws), stream()))
         return dx, None, None, None, None, None, None, None, None
 
 

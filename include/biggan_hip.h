@@ -111,7 +111,7 @@ int bg_gemm(const BgGemmDesc*, const float* A, const float* B, const float* bias
 /* --------------------------------------------------------------------------------------------
  * Spectral norm, one power iteration (ops.py:718-747).  W is [rows, cols] (= reshape(w,[-1,last])).
  *   v = l2n(u W^T), u_out = l2n(v W), sigma = |v W|, w_norm = W / sigma.
- *   l2n(t) = t * rsqrt(max(sum t^2, 1e-12)).  scratch: (rows + cols + 4) floats.
+ *   l2n(t) = t * rsqrt(max(sum t^2, 1e-12)).  scratch: bg_spectral_norm_workspace_bytes (fp64 accumulators).
  * bwd: dW = (G - <G, w_norm> v^T u_out) / sigma  (u_out, v stop-gradient, ops.py:738-739).
  * ------------------------------------------------------------------------------------------ */
 size_t bg_spectral_norm_workspace_bytes(int rows, int cols);
@@ -124,15 +124,16 @@ int bg_spectral_norm_bwd(const float* g_wnorm, const float* w_norm, const float*
 
 /* --------------------------------------------------------------------------------------------
  * Batch statistics + (conditional) batch-norm + PReLU (ops.py:532-537, 580-585, 611-643).
- *   x [N,HW,C].  stats: sums[0:C] = sum x, sums[C:2C] = sum x^2 over N*HW (fp32; caller zeroes or
+ *   x [N,HW,C].  stats: sums[0:C] = sum x, sums[C:2C] = sum x^2 over N*HW (fp64 accumulators, so the
+ *   result does not depend on the arrival order of the blocks' atomics; caller zeroes or
  *   all-reduces them for cross-replica BN), then bg_bn_finalize turns sums into mean / rstd
  *   (biased variance, eps) and updates the moving statistics.
  *   apply: y = act((x - mean) * rstd * gamma + beta), gamma/beta per sample [N,C] (per_sample=1,
  *   condition_batch_norm) or per channel [C] (tf.layers.batch_normalization);
  *   act = PReLU with per-channel alpha when alpha != NULL (ops.py:535-537), identity otherwise.
  * ------------------------------------------------------------------------------------------ */
-int bg_bn_stats(const float* x, float* sums, int64_t rows, int C, void* stream);
-int bg_bn_finalize(const float* sums, double count, float eps, float momentum, int unbiased_moving_var,
+int bg_bn_stats(const float* x, double* sums, int64_t rows, int C, void* stream);
+int bg_bn_finalize(const double* sums, double count, float eps, float momentum, int unbiased_moving_var,
                    float* mean, float* rstd, float* moving_mean, float* moving_var, int C, void* stream);
 int bg_bn_apply_act_fwd(const float* x, const float* mean, const float* rstd,
                         const float* gamma, const float* beta, int per_sample,
@@ -187,15 +188,15 @@ int bg_bias_grad(const float* dy, float* db, int64_t rows, int C, void* stream);
  * DiffAugment 'color,translation,cutout' (DiffAugment_tf.py:8-73), x [N,S,S,C] fp32.
  *   policy bit 0 = color, 1 = translation, 2 = cutout.  Draws are explicit device arrays:
  *   u_b,u_s,u_c float[N] in [0,1); t_x,t_y int32[N] in [-shift,shift]; o_x,o_y int32[N].
- *   mean_ws: N floats scratch (per-sample mean for rand_contrast).  Integer index math is
+ *   mean_ws: N doubles scratch (per-sample sums for rand_contrast).  Integer index math is
  *   bit-exact with DiffAugment_tf.py:40-66.
  * ------------------------------------------------------------------------------------------ */
 int bg_diffaugment_fwd(const float* x, float* y, const float* u_b, const float* u_s, const float* u_c,
                        const int32_t* t_x, const int32_t* t_y, const int32_t* o_x, const int32_t* o_y,
-                       int N, int S, int C, int policy, float* mean_ws, void* stream);
+                       int N, int S, int C, int policy, double* mean_ws, void* stream);
 int bg_diffaugment_bwd(const float* dy, float* dx, const float* u_s, const float* u_c,
                        const int32_t* t_x, const int32_t* t_y, const int32_t* o_x, const int32_t* o_y,
-                       int N, int S, int C, int policy, float* mean_ws, void* stream);
+                       int N, int S, int C, int policy, double* mean_ws, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Hinge losses with flood (ops.py:788-797, 832-840, 847-848).
