@@ -29,9 +29,14 @@ WORKLOADS = {
     "c2": (128, 64, 64, "BigGAN-128 ch=64 batch=64/GPU fp32 (BASELINE config 2)"),
     "c1": (64, 32, 16, "plumbing: BigGAN-64 ch=32 batch=16 fp32 (BASELINE config 1)"),
     "c3fp32": (128, 96, 32, "BigGAN-128 ch=96 batch=32/GPU fp32 (config 3 shape, fp32 kernels)"),
+    # bf16-compute conv / transposed-conv GEMMs (operands rounded to bf16 in LDS, fp32 accumulate, fp32 HBM tensors)
+    "c3": (128, 96, 32, "BigGAN-128 ch=96 batch=32/GPU (256 over 8 GPUs) bf16 conv compute (BASELINE config 3)"),
+    "c2bf16": (128, 64, 64, "BigGAN-128 ch=64 batch=64/GPU bf16 conv compute (config 2 shape)"),
 }
+BF16_WORKLOADS = ("c3", "c2bf16")
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2516.6     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 
 
 def step_flops_per_image(img, ch):
@@ -156,6 +161,9 @@ def main():
     argv = ["--gan_type", "hinge", "--img_size", str(img), "--ch", str(ch), "--batch_size", str(B),
             "--da_policy", a.da_policy, "--g_regularization", a.g_regularization]
     args = M.parse_args(argv, make_dirs=False)
+    bf16 = a.workload in BF16_WORKLOADS
+    hip.lib().bg_set_gemm_compute(1 if bf16 else 0)
+    peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
     gan = model.BigGAN(args, device="cuda", store=S.VariableStore("cuda", seed=42)).build_model()
     real = gan.synthetic_batch(B)
 
@@ -202,13 +210,15 @@ def main():
         note("roofline pass done")
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         fpi, fg, fd = step_flops_per_image(img, ch)
-        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "kernel": "bg::nn_kernel / bg::tn_kernel (fp32 MFMA implicit GEMM: conv, deconv, dense, attention)",
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "kernel": ("bg::nn_kernel_bf16 / bg::tn_kernel_bf16 (bf16 MFMA implicit GEMM: conv, deconv) + "
+                           "fp32 bg::nn_kernel for dense / attention / 1x1 launches that stay fp32") if bf16 else
+                          "bg::nn_kernel / bg::tn_kernel (fp32 MFMA implicit GEMM: conv, deconv, dense, attention)",
                 "launches_per_step": int(n.value // nprof), "gemm_ms_per_step": round(ms.value / nprof, 3),
                 "gemm_flops_per_step": fl.value / nprof,
                 "step_algorithmic_flops": fpi * B,
-                "step_frac_of_peak": round(fpi * B / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                "step_frac_of_peak": round(fpi * B / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -222,7 +232,7 @@ def main():
             "metric": "BigGAN-128 train-step images/sec" if img == 128 else "BigGAN-%d train-step images/sec" % img,
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": desc, "img_size": img, "ch": ch, "per_gpu_batch": B, "global_batch": B * world,
                        "da_policy": a.da_policy, "g_regularization": a.g_regularization,
                        "parallelism": "dp%d" % world},

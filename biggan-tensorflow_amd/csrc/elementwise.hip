@@ -45,7 +45,25 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(Fn fn, OutT* out, i
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc[q][j] = 0.f;
         if (cv < CV && rl < lanes) {
-            for (int64_t r = r0 + rl; r < r1; r += lanes) fn(seg, r, cv * VEC, acc);
+            // 4 independent partial sums keep 4 rows' loads in flight per thread (HBM latency hiding)
+            float acc4[4][NQ][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc4[u][q][j] = 0.f;
+            int64_t r = r0 + rl;
+            for (; r + 3 * (int64_t)lanes < r1; r += 4 * (int64_t)lanes) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fn(seg, r + u * (int64_t)lanes, cv * VEC, acc4[u]);
+            }
+            for (; r < r1; r += lanes) fn(seg, r, cv * VEC, acc4[0]);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    acc[q][j] = (acc4[0][q][j] + acc4[1][q][j]) + (acc4[2][q][j] + acc4[3][q][j]);
         }
         // combine row-lanes
 #pragma unroll

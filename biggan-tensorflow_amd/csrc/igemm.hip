@@ -13,137 +13,19 @@
 // Blocks are renumbered so that the tiles sharing operand panels run on one XCD (shared L2).
 #include "common.h"
 #include "igemm.h"
+#include "igemm_dev.h"
+#include "igemm_bf16.h"
+
+#include <atomic>
 
 namespace bg {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+// 0: fp32 MFMA (the reference's precision) ; 1: bf16 MFMA with fp32 accumulate for conv / transposed conv
+static std::atomic<int> g_gemm_compute{0};
+
 #define BKT 16  // K tile (floats)
-
-// ------------------------------------------------------------------------------------------
-// gather index math (shared by NN and TN kernels)
-// ------------------------------------------------------------------------------------------
-struct RowPos {
-    int b, ho, wo;
-    bool valid;
-};
-
-template <int MODE>
-__device__ __forceinline__ RowPos decompose_row(const Gather& g, int m, int M, int ph, int pw) {
-    RowPos r;
-    r.valid = m < M;
-    if (MODE == GATHER_PLAIN) {
-        r.b = m;
-        r.ho = 0;
-        r.wo = 0;
-        return r;
-    }
-    int wq = m % g.Wq;
-    int t = m / g.Wq;
-    int hq = t % g.Hq;
-    r.b = t / g.Hq;
-    r.ho = hq * g.pstep + ph;
-    r.wo = wq * g.pstep + pw;
-    return r;
-}
-
-// one axis of a CONV-mode gather: source index or -1
-__device__ __forceinline__ int conv_src(int o, int kk, int stride, int pad, int reflect, int n) {
-    int s = o * stride + kk - pad;
-    if (reflect) {
-        s = s < 0 ? -s : s;
-        s = s >= n ? 2 * (n - 1) - s : s;
-        return s;
-    }
-    return (s >= 0 && s < n) ? s : -1;
-}
-
-// one axis of a TCONV-mode gather: numerator hn = o + pad - kk must be a non-negative multiple of stride
-__device__ __forceinline__ int tconv_src_from_num(int hn, int stride, int n) {
-    if (hn < 0) return -1;
-    int s = stride == 1 ? hn : (hn >> 1);
-    if (stride != 1 && (hn & 1)) return -1;
-    return s < n ? s : -1;
-}
-
-// mirrored source of a TCONV gather with reflect padding (gradient of tf.pad(REFLECT) folded in):
-// the padded positions that alias output pixel o are  pad - o  (1 <= o <= pad)  and
-// 2*(n_out-1) + pad - o  (n_out-1-pad <= o <= n_out-2).
-__device__ __forceinline__ int tconv_mirror_src(int o, int kk, int stride, int pad, int n_out, int n_src) {
-    int hn;
-    if (o >= 1 && o <= pad)
-        hn = pad - o - kk;
-    else if (o >= n_out - 1 - pad && o <= n_out - 2)
-        hn = 2 * (n_out - 1) + pad - o - kk;
-    else
-        return -1;
-    return tconv_src_from_num(hn, stride, n_src);
-}
-
-// up to 4 source offsets (element offsets into the source tensor, -1 = none) for row r and tap (kh,kw)
-template <int MODE, bool MIRROR>
-__device__ __forceinline__ void tap_sources(const Gather& g, const RowPos& r, int kh, int kw,
-                                            int64_t (&off)[MIRROR ? 4 : 1]) {
-#pragma unroll
-    for (int i = 0; i < (MIRROR ? 4 : 1); ++i) off[i] = -1;
-    if (!r.valid) return;
-    if (MODE == GATHER_PLAIN) {
-        off[0] = (int64_t)r.b * g.ld;
-        return;
-    }
-    int h0, w0, h1 = -1, w1 = -1;
-    if (MODE == GATHER_CONV) {
-        h0 = conv_src(r.ho, kh, g.stride, g.pad, g.reflect, g.Hs);
-        w0 = conv_src(r.wo, kw, g.stride, g.pad, g.reflect, g.Ws);
-    } else {
-        h0 = tconv_src_from_num(r.ho + g.pad - kh, g.stride, g.Hs);
-        w0 = tconv_src_from_num(r.wo + g.pad - kw, g.stride, g.Ws);
-        if (MIRROR) {
-            h1 = tconv_mirror_src(r.ho, kh, g.stride, g.pad, g.Ho, g.Hs);
-            w1 = tconv_mirror_src(r.wo, kw, g.stride, g.pad, g.Wo, g.Ws);
-        }
-    }
-    const int64_t base = (int64_t)r.b * g.Hs;
-    if (h0 >= 0 && w0 >= 0) off[0] = ((base + h0) * g.Ws + w0) * g.ld;
-    if (MIRROR) {
-        if (h0 >= 0 && w1 >= 0) off[1] = ((base + h0) * g.Ws + w1) * g.ld;
-        if (h1 >= 0 && w0 >= 0) off[2] = ((base + h1) * g.Ws + w0) * g.ld;
-        if (h1 >= 0 && w1 >= 0) off[3] = ((base + h1) * g.Ws + w1) * g.ld;
-    }
-}
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-template <bool VEC>
-__device__ __forceinline__ float4 load_chan4(const float* base, int64_t off, int c, int C) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (off < 0) return v;
-    const float* p = base + off + c;
-    if (VEC) {
-        if (c < C) v = ld4(p);
-    } else {
-        if (c + 0 < C) v.x = p[0];
-        if (c + 1 < C) v.y = p[1];
-        if (c + 2 < C) v.z = p[2];
-        if (c + 3 < C) v.w = p[3];
-    }
-    return v;
-}
-
-__device__ __forceinline__ void add4(float4& a, const float4& b) {
-    a.x += b.x;
-    a.y += b.y;
-    a.z += b.z;
-    a.w += b.w;
-}
-
-// XCD-aware renumbering: hardware deals consecutive block ids round-robin over the 8 XCDs; give each
-// XCD a contiguous range of logical tiles so neighbouring tiles share one L2.  Bijective for any n.
-__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
-    const int q = nblocks >> 3, r = nblocks & 7;
-    const int x = bid & 7, j = bid >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-}
 
 // TM x TN MFMA tiles of one wave over one 16-deep K tile, operand reads software-pipelined
 template <int TM, int TN, int LDA, int LDB>
@@ -670,10 +552,19 @@ static void launch_nn_inst(const NNParams& p, bool vec, dim3 grid, hipStream_t s
 }
 
 template <bool BT, int MODE, bool MIRROR>
-static void launch_nn_tile(NNParams& p, const NNPlan& pl, bool vec, int zdim, hipStream_t s) {
+static void launch_nn_tile(NNParams& p, const NNPlan& pl, bool vec, bool bf16, int zdim, hipStream_t s) {
     p.tiles_m = (p.M + pl.bm - 1) / pl.bm;
     p.tiles_n = (p.N + pl.bn - 1) / pl.bn;
     dim3 grid(p.tiles_m * p.tiles_n, 1, zdim * p.splitk);
+    if (bf16 && vec && pl.bn >= 64) {
+        if (pl.bm == 128 && pl.bn == 128)
+            hipLaunchKernelGGL((nn_kernel_bf16<2, 2, BT, MODE, MIRROR>), grid, dim3(256), 0, s, p);
+        else if (pl.bm == 128 && pl.bn == 64)
+            hipLaunchKernelGGL((nn_kernel_bf16<2, 1, BT, MODE, MIRROR>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((nn_kernel_bf16<1, 1, BT, MODE, MIRROR>), grid, dim3(256), 0, s, p);
+        return;
+    }
     if (pl.bm == 128 && pl.bn == 128)
         launch_nn_inst<2, 2, 2, 2, BT, MODE, MIRROR>(p, vec, grid, s);
     else if (pl.bm == 128 && pl.bn == 64)
@@ -691,7 +582,9 @@ static size_t nn_workspace_bytes(int64_t M, int N, int zdim, int niter_min, int6
 
 // the (MODE, BT) pairs that exist: CONV/BT0, TCONV/BT1 (+MIRROR), PLAIN/BT0, PLAIN/BT1
 static int launch_nn(NNParams& p, int mode, bool bt, bool mirror, bool vec, int zdim, int niter_min,
-                     int64_t out_elems, bool out_dense, void* ws, size_t ws_bytes, hipStream_t s) {
+                     int64_t out_elems, bool out_dense, void* ws, size_t ws_bytes, hipStream_t s,
+                     bool allow_bf16 = false) {
+    const bool bf16 = allow_bf16 && g_gemm_compute.load() == 1;
     NNPlan pl = plan_nn(p.M, p.N, zdim, niter_min, out_dense && ws != nullptr);
     if (pl.splitk > 1 && ws_bytes < (size_t)pl.splitk * out_elems * sizeof(float)) {
         pl = plan_nn(p.M, p.N, zdim, niter_min, false);
@@ -700,15 +593,15 @@ static int launch_nn(NNParams& p, int mode, bool bt, bool mirror, bool vec, int 
     p.slabs = reinterpret_cast<float*>(ws);
     p.slab_stride = out_elems;
     if (mode == GATHER_CONV)
-        launch_nn_tile<false, GATHER_CONV, false>(p, pl, vec, zdim, s);
+        launch_nn_tile<false, GATHER_CONV, false>(p, pl, vec, bf16, zdim, s);
     else if (mode == GATHER_TCONV && mirror)
-        launch_nn_tile<true, GATHER_TCONV, true>(p, pl, vec, zdim, s);
+        launch_nn_tile<true, GATHER_TCONV, true>(p, pl, vec, bf16, zdim, s);
     else if (mode == GATHER_TCONV)
-        launch_nn_tile<true, GATHER_TCONV, false>(p, pl, vec, zdim, s);
+        launch_nn_tile<true, GATHER_TCONV, false>(p, pl, vec, bf16, zdim, s);
     else if (bt)
-        launch_nn_tile<true, GATHER_PLAIN, false>(p, pl, vec, zdim, s);
+        launch_nn_tile<true, GATHER_PLAIN, false>(p, pl, vec, false, zdim, s);
     else
-        launch_nn_tile<false, GATHER_PLAIN, false>(p, pl, vec, zdim, s);
+        launch_nn_tile<false, GATHER_PLAIN, false>(p, pl, vec, false, zdim, s);
     BG_LAUNCH_CHECK();
     if (pl.splitk > 1) {
         int blocks = (int)((out_elems + 255) / 256);
@@ -768,7 +661,9 @@ static void launch_tn_inst(const TNParams& p, int mode, bool vec, dim3 grid, hip
 }
 
 // out must be a dense [batch][Mf][Cb] block when split-K is used
-static int launch_tn(TNParams& p, int mode, bool vec, float* final_out, void* ws, size_t ws_bytes, hipStream_t s) {
+static int launch_tn(TNParams& p, int mode, bool vec, float* final_out, void* ws, size_t ws_bytes, hipStream_t s,
+                     bool allow_bf16 = false) {
+    const bool bf16 = allow_bf16 && vec && mode == GATHER_CONV && g_gemm_compute.load() == 1;
     TNPlan pl = plan_tn(p.Mf, p.Cb, p.batch, p.M);
     const int64_t total = (int64_t)p.batch * p.Mf * p.Cb;
     const bool dense = (p.out_ld == p.Cb) && (p.batch == 1 || p.strideC == (int64_t)p.Mf * p.Cb);
@@ -788,7 +683,14 @@ static int launch_tn(TNParams& p, int mode, bool vec, float* final_out, void* ws
     p.tiles_m = (p.Mf + pl.bm - 1) / pl.bm;
     p.tiles_n = (p.Cb + pl.bn - 1) / pl.bn;
     dim3 grid(p.tiles_m * p.tiles_n, 1, p.batch * p.splitk);
-    if (pl.bm == 128 && pl.bn == 128)
+    if (bf16 && pl.bn >= 64) {
+        if (pl.bm == 128 && pl.bn == 128)
+            hipLaunchKernelGGL((tn_kernel_bf16<2, 2, GATHER_CONV>), grid, dim3(256), 0, s, p);
+        else if (pl.bm == 128 && pl.bn == 64)
+            hipLaunchKernelGGL((tn_kernel_bf16<2, 1, GATHER_CONV>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((tn_kernel_bf16<1, 1, GATHER_CONV>), grid, dim3(256), 0, s, p);
+    } else if (pl.bm == 128 && pl.bn == 128)
         launch_tn_inst<2, 2, 2, 2>(p, mode, vec, grid, s);
     else if (pl.bm == 128 && pl.bn == 64)
         launch_tn_inst<2, 1, 2, 2>(p, mode, vec, grid, s);
@@ -918,6 +820,9 @@ using namespace bg;
 
 extern "C" {
 
+void bg_set_gemm_compute(int mode) { g_gemm_compute.store(mode == 1 ? 1 : 0); }
+int bg_get_gemm_compute(void) { return g_gemm_compute.load(); }
+
 size_t bg_conv2d_fwd_workspace_bytes(const BgConvDesc* d) {
     if (!d) return 0;
     return nn_workspace_bytes((int64_t)d->N * d->Ho * d->Wo, d->Cout, 1, d->k * d->k * kc_of(d->Cin),
@@ -935,7 +840,7 @@ int bg_conv2d_fwd(const BgConvDesc* d, const float* x, const float* w, const flo
     Tag tag("conv2d_fwd", d);
     ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
     return launch_nn(p, GATHER_CONV, false, false, vec, 1, d->k * d->k * kc_of(d->Cin),
-                     (int64_t)p.M * d->Cout, true, ws, ws_bytes, as_stream(stream));
+                     (int64_t)p.M * d->Cout, true, ws, ws_bytes, as_stream(stream), true);
 }
 
 size_t bg_conv2d_dgrad_workspace_bytes(const BgConvDesc* d) {
@@ -957,7 +862,7 @@ int bg_conv2d_dgrad(const BgConvDesc* d, const float* dy, const float* w, const 
     Tag tag("conv2d_dgrad", d);
     ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
     return launch_nn(p, GATHER_TCONV, true, p.g.reflect != 0, vec, d->stride * d->stride, tconv_min_iters(d, d->Cout),
-                     (int64_t)d->N * d->H * d->W * d->Cin, true, ws, ws_bytes, as_stream(stream));
+                     (int64_t)d->N * d->H * d->W * d->Cin, true, ws, ws_bytes, as_stream(stream), true);
 }
 
 size_t bg_conv2d_wgrad_workspace_bytes(const BgConvDesc* d) {
@@ -980,7 +885,7 @@ int bg_conv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, float*
     const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(dy);
     Tag tag("conv2d_wgrad", d);
     ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
-    return launch_tn(p, GATHER_CONV, vec, dw, ws, ws_bytes, as_stream(stream));
+    return launch_tn(p, GATHER_CONV, vec, dw, ws, ws_bytes, as_stream(stream), true);
 }
 
 size_t bg_deconv2d_fwd_workspace_bytes(const BgConvDesc* d) {
@@ -1001,7 +906,7 @@ int bg_deconv2d_fwd(const BgConvDesc* d, const float* x, const float* w, const f
     Tag tag("deconv2d_fwd", d);
     ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
     return launch_nn(p, GATHER_TCONV, true, false, vec, d->stride * d->stride, tconv_min_iters(d, d->Cin),
-                     (int64_t)d->N * d->Ho * d->Wo * d->Cout, true, ws, ws_bytes, as_stream(stream));
+                     (int64_t)d->N * d->Ho * d->Wo * d->Cout, true, ws, ws_bytes, as_stream(stream), true);
 }
 
 size_t bg_deconv2d_dgrad_workspace_bytes(const BgConvDesc* d) {
@@ -1021,7 +926,7 @@ int bg_deconv2d_dgrad(const BgConvDesc* d, const float* dy, const float* w, cons
     Tag tag("deconv2d_dgrad", d);
     ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
     return launch_nn(p, GATHER_CONV, false, false, vec, 1, d->k * d->k * kc_of(d->Cout),
-                     (int64_t)p.M * d->Cin, true, ws, ws_bytes, as_stream(stream));
+                     (int64_t)p.M * d->Cin, true, ws, ws_bytes, as_stream(stream), true);
 }
 
 size_t bg_deconv2d_wgrad_workspace_bytes(const BgConvDesc* d) {
@@ -1045,7 +950,7 @@ int bg_deconv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, floa
     const bool vec = (d->Cout % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy) && aligned16(x);
     Tag tag("deconv2d_wgrad", d);
     ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
-    return launch_tn(p, GATHER_CONV, vec, dw, ws, ws_bytes, as_stream(stream));
+    return launch_tn(p, GATHER_CONV, vec, dw, ws, ws_bytes, as_stream(stream), true);
 }
 
 size_t bg_gemm_workspace_bytes(const BgGemmDesc* d) {

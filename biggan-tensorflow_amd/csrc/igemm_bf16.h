@@ -1,0 +1,438 @@
+// igemm_bf16.h - bf16-compute variants of the two implicit-GEMM kernels (v_mfma_f32_32x32x16_bf16,
+// fp32 accumulate).  Activations, weights and outputs stay fp32 in HBM (the reference's dtype,
+// ops.py:14); operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) while they are staged into LDS.
+// This is the first step towards BASELINE config 3 (bf16): the MFMA rate is 16x the fp32 one, so
+// these kernels are bound by operand traffic (L2 -> LDS), not by the matrix pipe.
+//
+// LDS images are [row][k] with 32 bf16 (64 B) of payload per row padded to 80 B: the 16-byte operand
+// reads of a 32x32x16 MFMA (lane = row, 8 consecutive k) then hit 16 distinct 4-bank groups per
+// 16-lane read group, and the transposing 8-byte writes (lanes 0-7 consecutive k, lanes 8-15 the next
+// row quad, 4 * 20 dwords = 16 mod 32) are conflict-free as well.
+#pragma once
+#include "igemm_dev.h"
+
+namespace bg {
+
+typedef float floatx16_b __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define BKB 32       // K tile (elements)
+#define LROW 40      // bf16 elements per LDS row (80 bytes)
+
+__device__ __forceinline__ bf16x8 cvt8(const float4& a, const float4& b) {
+    bf16x8 r;
+    r[0] = (__bf16)a.x; r[1] = (__bf16)a.y; r[2] = (__bf16)a.z; r[3] = (__bf16)a.w;
+    r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
+    return r;
+}
+
+__device__ __forceinline__ bf16x4 cvt4(float a, float b, float c, float d) {
+    bf16x4 r;
+    r[0] = (__bf16)a; r[1] = (__bf16)b; r[2] = (__bf16)c; r[3] = (__bf16)d;
+    return r;
+}
+
+// TM x TN MFMA tiles over one 32-deep K tile: 2 k-steps of 16
+template <int TM, int TN>
+__device__ __forceinline__ void mma_tile_bf16(const __bf16* __restrict__ as, const __bf16* __restrict__ bs, int a_rd,
+                                              int b_rd, floatx16_b (&acc)[TM][TN]) {
+#pragma unroll
+    for (int s = 0; s < BKB / 16; ++s) {
+        bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + a_rd + 32 * i * LROW + s * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + b_rd + 32 * j * LROW + s * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// NN kernel, bf16 compute (vector path only: C % 4 == 0, 16-byte aligned operands)
+// ------------------------------------------------------------------------------------------
+template <int TM, int TN, bool BT, int MODE, bool MIRROR>
+__global__ __launch_bounds__(256) void nn_kernel_bf16(const NNParams p) {
+    constexpr int WN = 2;
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int AITEMS = BM * 4 / 256;            // (row, k8) items per thread
+    constexpr int NSRC = MIRROR ? 4 : 1;
+    constexpr int BITEMS_T = BN * 4 / 256;          // BT: (n, k8) items per thread
+    constexpr int BPATCH = (BKB / 4) * (BN / 4);    // non-BT: 4k x 4n patches in the tile
+    constexpr int BITEMS_N = (BPATCH + 255) / 256;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * LROW];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * LROW];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const Gather& g = p.g;
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int zs = blockIdx.z % p.splitk, zo = blockIdx.z / p.splitk;
+    const float* Abase = p.A;
+    const float* Bbase = p.B;
+    float* Obase = p.out;
+    int ph = 0, pw = 0;
+    if (MODE == GATHER_PLAIN) {
+        Abase += (int64_t)zo * p.strideA;
+        Bbase += (int64_t)zo * p.strideB;
+        Obase += (int64_t)zo * p.strideC;
+    } else if (MODE == GATHER_TCONV) {
+        ph = g.pstep - 1 - zo / g.pstep;
+        pw = g.pstep - 1 - zo % g.pstep;
+    }
+    int kh0 = 0, kw0 = 0, kstep = 1, nkh = g.k, nkw = g.k;
+    if (MODE == GATHER_TCONV && g.pstep > 1) {
+        kstep = g.stride;
+        kh0 = (ph + g.pad) % g.stride;
+        kw0 = (pw + g.pad) % g.stride;
+        nkh = (g.k - kh0 + g.stride - 1) / g.stride;
+        nkw = (g.k - kw0 + g.stride - 1) / g.stride;
+    }
+    if (MODE == GATHER_PLAIN) {
+        nkh = 1;
+        nkw = 1;
+    }
+    const int kc = (p.C + BKB - 1) / BKB;
+    const int niter_all = nkh * nkw * kc;
+    const int ips = (niter_all + p.splitk - 1) / p.splitk;
+    const int it0 = zs * ips;
+    const int it1 = min(niter_all, it0 + ips);
+    const int niter = max(0, it1 - it0);
+
+    const int a_k8 = (t & 3) * 8;
+    RowPos rows[AITEMS];
+#pragma unroll
+    for (int i = 0; i < AITEMS; ++i) rows[i] = decompose_row<MODE>(g, m0 + (t >> 2) + 64 * i, p.M, ph, pw);
+    int64_t aoff[AITEMS][NSRC];
+
+    int l_ic = it0 % kc;
+    int l_iw = (it0 / kc) % nkw;
+    int l_ih = (it0 / kc) / nkw;
+    bool need_off = true;
+    float4 ra[AITEMS][2];
+    constexpr int BREG = BT ? BITEMS_T * 2 : BITEMS_N * 4;
+    float4 rb[BREG];
+
+    auto load_tile = [&]() {
+        const int kh = kh0 + l_ih * kstep, kw = kw0 + l_iw * kstep;
+        if (need_off || l_ic == 0) {
+#pragma unroll
+            for (int i = 0; i < AITEMS; ++i) tap_sources<MODE, MIRROR>(g, rows[i], kh, kw, aoff[i]);
+            need_off = false;
+        }
+        const int c0 = l_ic * BKB;
+#pragma unroll
+        for (int i = 0; i < AITEMS; ++i) {
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                float4 v = load_chan4<true>(Abase, aoff[i][0], c0 + a_k8 + 4 * hlf, p.C);
+                if (MIRROR) {
+#pragma unroll
+                    for (int s = 1; s < NSRC; ++s)
+                        add4(v, load_chan4<true>(Abase, aoff[i][s], c0 + a_k8 + 4 * hlf, p.C));
+                }
+                ra[i][hlf] = v;
+            }
+        }
+        const float* wt = Bbase + (int64_t)(kh * g.k + kw) * p.tap_stride;
+        if (BT) {
+#pragma unroll
+            for (int i = 0; i < BITEMS_T; ++i) {
+                const int n = n0 + (t >> 2) + 64 * i;
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const int c = c0 + a_k8 + 4 * hlf;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (n < p.N && c < p.C) v = ld4(wt + (int64_t)n * p.ldn + c);
+                    rb[i * 2 + hlf] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BITEMS_N; ++i) {
+                const int idx = t + 256 * i;
+                const int k4 = idx & 7, nq = idx >> 3;          // lanes 0-7: consecutive k quads
+                const int n = n0 + nq * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + k4 * 4 + j;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (idx < BPATCH && c < p.C && n < p.N) v = ld4(wt + (int64_t)c * p.ldk + n);
+                    rb[i * 4 + j] = v;
+                }
+            }
+        }
+        if (++l_ic == kc) {
+            l_ic = 0;
+            if (++l_iw == nkw) {
+                l_iw = 0;
+                ++l_ih;
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        __bf16* as = As[buf];
+        __bf16* bs = Bs[buf];
+#pragma unroll
+        for (int i = 0; i < AITEMS; ++i) {
+            const int r = (t >> 2) + 64 * i;
+            *reinterpret_cast<bf16x8*>(as + r * LROW + a_k8) = cvt8(ra[i][0], ra[i][1]);
+        }
+        if (BT) {
+#pragma unroll
+            for (int i = 0; i < BITEMS_T; ++i) {
+                const int n = (t >> 2) + 64 * i;
+                *reinterpret_cast<bf16x8*>(bs + n * LROW + a_k8) = cvt8(rb[i * 2], rb[i * 2 + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BITEMS_N; ++i) {
+                const int idx = t + 256 * i;
+                if (idx < BPATCH) {
+                    const int k4 = idx & 7, nq = idx >> 3;
+                    const float4 r0 = rb[i * 4], r1 = rb[i * 4 + 1], r2 = rb[i * 4 + 2], r3 = rb[i * 4 + 3];
+                    __bf16* base = bs + (nq * 4) * LROW + k4 * 4;
+                    *reinterpret_cast<bf16x4*>(base) = cvt4(r0.x, r1.x, r2.x, r3.x);
+                    *reinterpret_cast<bf16x4*>(base + LROW) = cvt4(r0.y, r1.y, r2.y, r3.y);
+                    *reinterpret_cast<bf16x4*>(base + 2 * LROW) = cvt4(r0.z, r1.z, r2.z, r3.z);
+                    *reinterpret_cast<bf16x4*>(base + 3 * LROW) = cvt4(r0.w, r1.w, r2.w, r3.w);
+                }
+            }
+        }
+    };
+
+    floatx16_b acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (niter > 0) {
+        load_tile();
+        store_tile(0);
+    }
+    __syncthreads();
+
+    // operand reads: lane l -> row (l & 31), k offset 8 * (l >> 5)
+    const int a_rd = (wm * 32 * TM + (lane & 31)) * LROW + (lane >> 5) * 8;
+    const int b_rd = (wn * 32 * TN + (lane & 31)) * LROW + (lane >> 5) * 8;
+
+    for (int it = 0; it < niter; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < niter) load_tile();
+        mma_tile_bf16<TM, TN>(As[cur], Bs[cur], a_rd, b_rd, acc);
+        if (it + 1 < niter) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    const bool partial = p.splitk > 1;
+    const float alpha = (!partial && p.alpha) ? *p.alpha : 1.0f;
+    if (partial) Obase = p.slabs + (int64_t)zs * p.slab_stride + (Obase - p.out);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= p.M) continue;
+            int64_t ooff;
+            if (MODE != GATHER_TCONV) {
+                ooff = (int64_t)row * p.out_ld;
+            } else {
+                RowPos rp = decompose_row<MODE>(g, row, p.M, ph, pw);
+                ooff = (((int64_t)rp.b * g.Ho + rp.ho) * g.Wo + rp.wo) * p.out_ld;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * 32 * TN + 32 * j + (lane & 31);
+                if (col < p.N) {
+                    float v = acc[i][j][r] * alpha;
+                    float* o = Obase + ooff + col;
+                    if (!partial) {
+                        if (p.bias) v += p.bias[col];
+                        if (p.accumulate) v += *o;
+                    }
+                    *o = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN kernel, bf16 compute: out[(tap, ca)][cb] = sum_pixels A(pixel, tap)[ca] * Bv(pixel)[cb]
+// both operands are transposed on the way into LDS ([channel][pixel] images)
+// ------------------------------------------------------------------------------------------
+template <int TM, int TN, int MODE>
+__global__ __launch_bounds__(256) void tn_kernel_bf16(const TNParams p) {
+    constexpr int WN = 2;
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int APATCH = (BKB / 4) * (BM / 4), BPATCH = (BKB / 4) * (BN / 4);
+    constexpr int AIT = (APATCH + 255) / 256, BIT = (BPATCH + 255) / 256;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * LROW];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * LROW];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const Gather& g = p.g;
+
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    const int mf0 = tile_m * BM, cb0 = tile_n * BN;
+    const int zb = blockIdx.z / p.splitk, zs = blockIdx.z % p.splitk;
+    const float* Abase = p.A + (int64_t)zb * p.strideA;
+    const float* Bbase = p.Bv + (int64_t)zb * p.strideB;
+
+    const int row_begin = zs * p.rows_per_split;
+    const int row_end = min(p.M, row_begin + p.rows_per_split);
+    const int niter = max(0, (row_end - row_begin + BKB - 1) / BKB);
+
+    // patch (k4, cq): pixels l_row + 4*k4 .. +3, channels 4*cq .. +3 ; lanes 0-7 take consecutive k4
+    int a_kh[AIT], a_kw[AIT], a_c[AIT];
+    RowPos apos[AIT][4];
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+        const int idx = t + 256 * i;
+        const int k4 = idx & 7, cq = idx >> 3;
+        const int mf = mf0 + cq * 4;
+        int tap = 0, c = mf;
+        if (MODE != GATHER_PLAIN) {
+            tap = mf / p.Ca;
+            c = mf - tap * p.Ca;
+        }
+        a_kh[i] = tap / g.k;
+        a_kw[i] = tap % g.k;
+        a_c[i] = (idx < APATCH && mf < p.Mf) ? c : -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) apos[i][j] = decompose_row<MODE>(g, row_begin + k4 * 4 + j, p.M, 0, 0);
+    }
+
+    float4 ra[AIT][4], rb[BIT][4];
+    int l_row = row_begin;
+
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            const int k4 = (t + 256 * i) & 7;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = l_row + k4 * 4 + j;
+                RowPos rp = apos[i][j];
+                rp.valid = m < p.M;
+                if (MODE == GATHER_PLAIN) {
+                    apos[i][j].b += BKB;
+                } else {
+                    apos[i][j].wo += BKB;
+                    while (apos[i][j].wo >= g.Wq) {
+                        apos[i][j].wo -= g.Wq;
+                        if (++apos[i][j].ho == g.Hq) {
+                            apos[i][j].ho = 0;
+                            ++apos[i][j].b;
+                        }
+                    }
+                }
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a_c[i] >= 0 && m < row_end) {
+                    int64_t off[1];
+                    tap_sources<MODE, false>(g, rp, a_kh[i], a_kw[i], off);
+                    v = load_chan4<true>(Abase, off[0], a_c[i], p.Ca);
+                }
+                ra[i][j] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            const int idx = t + 256 * i;
+            const int k4 = idx & 7, cq = idx >> 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = l_row + k4 * 4 + j;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < BPATCH && m < row_end) v = load_chan4<true>(Bbase, (int64_t)m * p.b_ld, cb0 + cq * 4, p.Cb);
+                rb[i][j] = v;
+            }
+        }
+        l_row += BKB;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            const int idx = t + 256 * i;
+            if (idx < APATCH) {
+                const int k4 = idx & 7, cq = idx >> 3;
+                __bf16* base = As[buf] + (cq * 4) * LROW + k4 * 4;
+                *reinterpret_cast<bf16x4*>(base) = cvt4(ra[i][0].x, ra[i][1].x, ra[i][2].x, ra[i][3].x);
+                *reinterpret_cast<bf16x4*>(base + LROW) = cvt4(ra[i][0].y, ra[i][1].y, ra[i][2].y, ra[i][3].y);
+                *reinterpret_cast<bf16x4*>(base + 2 * LROW) = cvt4(ra[i][0].z, ra[i][1].z, ra[i][2].z, ra[i][3].z);
+                *reinterpret_cast<bf16x4*>(base + 3 * LROW) = cvt4(ra[i][0].w, ra[i][1].w, ra[i][2].w, ra[i][3].w);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            const int idx = t + 256 * i;
+            if (idx < BPATCH) {
+                const int k4 = idx & 7, cq = idx >> 3;
+                __bf16* base = Bs[buf] + (cq * 4) * LROW + k4 * 4;
+                *reinterpret_cast<bf16x4*>(base) = cvt4(rb[i][0].x, rb[i][1].x, rb[i][2].x, rb[i][3].x);
+                *reinterpret_cast<bf16x4*>(base + LROW) = cvt4(rb[i][0].y, rb[i][1].y, rb[i][2].y, rb[i][3].y);
+                *reinterpret_cast<bf16x4*>(base + 2 * LROW) = cvt4(rb[i][0].z, rb[i][1].z, rb[i][2].z, rb[i][3].z);
+                *reinterpret_cast<bf16x4*>(base + 3 * LROW) = cvt4(rb[i][0].w, rb[i][1].w, rb[i][2].w, rb[i][3].w);
+            }
+        }
+    };
+
+    floatx16_b acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (niter > 0) {
+        load_tile();
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int a_rd = (wm * 32 * TM + (lane & 31)) * LROW + (lane >> 5) * 8;
+    const int b_rd = (wn * 32 * TN + (lane & 31)) * LROW + (lane >> 5) * 8;
+
+    for (int it = 0; it < niter; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < niter) load_tile();
+        mma_tile_bf16<TM, TN>(As[cur], Bs[cur], a_rd, b_rd, acc);
+        if (it + 1 < niter) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    const float alpha = p.alpha ? *p.alpha : 1.0f;
+    float* obase = p.out + (int64_t)zb * p.strideC + (int64_t)zs * p.slab_stride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mf0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= p.Mf) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = cb0 + wn * 32 * TN + 32 * j + (lane & 31);
+                if (col < p.Cb) obase[(int64_t)row * p.out_ld + col] = acc[i][j][r] * alpha;
+            }
+        }
+    }
+}
+
+}  // namespace bg

@@ -37,6 +37,8 @@ SIGNATURES = {
     "bg_abi_version": (c_int, []),
     "bg_last_error": (c_char_p, []),
     "bg_target_arch": (c_char_p, []),
+    "bg_set_gemm_compute": (None, [c_int]),
+    "bg_get_gemm_compute": (c_int, []),
     "bg_conv2d_fwd_workspace_bytes": (c_size_t, [_CD]),
     "bg_conv2d_fwd": (c_int, [_CD, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "bg_conv2d_dgrad_workspace_bytes": (c_size_t, [_CD]),

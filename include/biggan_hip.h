@@ -48,6 +48,13 @@ typedef struct BgConvDesc {
     int32_t pad_mode;          /* BG_PAD_REFLECT (tf.pad REFLECT + VALID, ops.py:82) or BG_PAD_ZERO */
 } BgConvDesc;
 
+/* Compute precision of the conv / transposed-conv entry points (process-wide):
+ *   0 = fp32 MFMA (default; the reference's precision, ops.py:14)
+ *   1 = bf16 MFMA with fp32 accumulation: operands are rounded to bf16 (RNE) while they are staged
+ *       into LDS; tensors in HBM, outputs, dense layers, attention and every other kernel stay fp32. */
+void bg_set_gemm_compute(int mode);
+int  bg_get_gemm_compute(void);
+
 /* Every MFMA GEMM entry point takes caller-provided scratch (ws, ws_bytes) sized by the matching
  * *_workspace_bytes(): it holds split-K partial slabs for layers whose output is too small to fill
  * the chip (4x4 / 8x8 feature maps, weight gradients).  ws may be NULL: the kernel then runs
