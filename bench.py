@@ -129,6 +129,26 @@ def cpu_baseline(img, ch, sample_batch, steps, note=lambda m: None):
                       "TensorFlow, the reference's substrate, is not installed)" % (steps, sample_batch, dt)}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per implicit-GEMM launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    over this same command (profiles/README.md; counters cannot be read from inside the process)."""
+    import glob
+    import re
+    base = {"c2bf16": "c2", "c3fp32": "c3"}.get(workload, workload)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % workload)) or
+                   glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % base)))
+    if not files or not files[-1].endswith("_pmc_%s.json" % workload):
+        return None, None
+    with open(files[-1]) as fh:
+        d = json.load(fh)
+    n = b = 0.0
+    for k, e in d.items():
+        if re.search(r"\b(nn|tn)_kernel", k) and "hbm_read_bytes_per_launch" in e:
+            n += e["launches"]
+            b += e["launches"] * (e["hbm_read_bytes_per_launch"] + e.get("hbm_write_bytes_per_launch", 0.0))
+    return (b / n if n else None), os.path.relpath(files[-1], ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,8 +230,10 @@ def main():
         note("roofline pass done")
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         fpi, fg, fd = step_flops_per_image(img, ch)
+        traffic, traffic_src = pmc_traffic(a.workload)
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
+                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                "traffic_source": traffic_src,
                 "kernel": ("bg::nn_kernel_bf16 / bg::tn_kernel_bf16 (bf16 MFMA implicit GEMM: conv, deconv) + "
                            "fp32 bg::nn_kernel for dense / attention / 1x1 launches that stay fp32") if bf16 else
                           "bg::nn_kernel / bg::tn_kernel (fp32 MFMA implicit GEMM: conv, deconv, dense, attention)",
