@@ -596,12 +596,12 @@ __global__ __launch_bounds__(EW_BLOCK) void tanh_bwd_kernel(const float* __restr
 // spectral norm (ops.py:718-747)
 // scratch layout (floats): [0]=sum v_^2, [1]=sigma, [2]=rs_v, [3]=<G,Wn>; [4 .. 4+rows) = v_ ; then cols of u_raw
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(EW_BLOCK) void sn_rowdot_kernel(const float* __restrict__ w,
-                                                              const float* __restrict__ u, float* __restrict__ vraw,
-                                                              double* ssv, int rows, int cols) {
+__device__ __forceinline__ void sn_rowdot_body(const float* __restrict__ w, const float* __restrict__ u,
+                                               float* __restrict__ vraw, double* ssv, int rows, int cols, int bid,
+                                               int nblocks) {
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 4;
+    const int wave = bid * 4 + (threadIdx.x >> 6);
+    const int nwaves = nblocks * 4;
     double ss = 0.0;
     for (int r = wave; r < rows; r += nwaves) {
         const float* wr = w + (int64_t)r * cols;
@@ -623,6 +623,12 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_rowdot_kernel(const float* __rest
     // fp64 accumulation: the sum is the same to ~1e-16 whatever the arrival order of the waves, so
     // the forward pass is reproducible from run to run
     if (lane == 0 && ss != 0.0) atomicAdd(ssv, ss);
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void sn_rowdot_kernel(const float* __restrict__ w,
+                                                              const float* __restrict__ u, float* __restrict__ vraw,
+                                                              double* ssv, int rows, int cols) {
+    sn_rowdot_body(w, u, vraw, ssv, rows, cols, blockIdx.x, gridDim.x);
 }
 
 // out[r] = sum_c W[r][c] * v[c]   (one wave per row; v == nullptr: plain row sums)
@@ -653,22 +659,37 @@ __global__ __launch_bounds__(EW_BLOCK) void gemv_rows_kernel(const float* __rest
 }
 
 // uraw[c] += sum_{r in chunk} vraw[r] * W[r][c]
-__global__ __launch_bounds__(EW_BLOCK) void sn_colsum_kernel(const float* __restrict__ w,
-                                                              const float* __restrict__ vraw, double* uraw, int rows,
-                                                              int cols, int rows_per_block) {
-    const int r0 = blockIdx.y * rows_per_block;
+__device__ __forceinline__ void sn_colsum_body(const float* __restrict__ w, const float* __restrict__ vraw,
+                                               double* uraw, int rows, int cols, int rows_per_block, int cb, int rc) {
+    const int r0 = rc * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
-    const int c = blockIdx.x * EW_BLOCK + threadIdx.x;
+    const int c = cb * EW_BLOCK + threadIdx.x;
     if (c >= cols) return;
     float s = 0.f;
     for (int r = r0; r < r1; ++r) s += vraw[r] * w[(int64_t)r * cols + c];
     atomicAdd(&uraw[c], (double)s);
 }
 
+// split of the [rows, cols] column reduction into (column block, row chunk) work units
+__host__ __device__ inline void sn_colsum_plan(int rows, int cols, int* cblocks, int* rpb, int* rchunks) {
+    const int cb = (cols + EW_BLOCK - 1) / EW_BLOCK;
+    int rch = (512 + cb - 1) / cb;
+    int r = (rows + rch - 1) / rch;
+    if (r < 8) r = 8;
+    *cblocks = cb;
+    *rpb = r;
+    *rchunks = (rows + r - 1) / r;
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void sn_colsum_kernel(const float* __restrict__ w,
+                                                              const float* __restrict__ vraw, double* uraw, int rows,
+                                                              int cols, int rows_per_block) {
+    sn_colsum_body(w, vraw, uraw, rows, cols, rows_per_block, blockIdx.x, blockIdx.y);
+}
+
 // single block: norms, u_out, sigma.  scr (doubles): [0] = sum v_^2, [1] = sigma, [2] = rs_v
-__global__ __launch_bounds__(EW_BLOCK) void sn_finalize_kernel(double* scr, const double* uraw, float* u_out,
-                                                                float* sigma_out, int cols) {
-    __shared__ float sh[4];
+__device__ __forceinline__ void sn_finalize_body(double* scr, const double* uraw, float* u_out, float* sigma_out,
+                                                 int cols, float* sh) {
     const float rs_v = rsqrtf(fmaxf((float)scr[0], 1e-12f));       // l2_normalize(v_)
     float ss = 0.f;
     for (int c = threadIdx.x; c < cols; c += EW_BLOCK) {
@@ -686,20 +707,32 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_finalize_kernel(double* scr, cons
     }
 }
 
-__global__ __launch_bounds__(EW_BLOCK) void sn_normalize_kernel(const float* __restrict__ w, const double* scr,
-                                                                 const float* vraw, float* __restrict__ wn,
-                                                                 float* v_out, int64_t n, int rows) {
+__global__ __launch_bounds__(EW_BLOCK) void sn_finalize_kernel(double* scr, const double* uraw, float* u_out,
+                                                                float* sigma_out, int cols) {
+    __shared__ float sh[4];
+    sn_finalize_body(scr, uraw, u_out, sigma_out, cols, sh);
+}
+
+__device__ __forceinline__ void sn_normalize_body(const float* __restrict__ w, const double* scr, const float* vraw,
+                                                  float* __restrict__ wn, float* v_out, int64_t n, int rows,
+                                                  int bid, int nblocks) {
     const float sigma = (float)scr[1];
     const float rs_v = (float)scr[2];
     const int64_t n4 = n / 4;
-    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+    for (int64_t i = (int64_t)bid * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)nblocks * EW_BLOCK) {
         float4 a = ldg4(w + i * 4);
         stg4(wn + i * 4, make_float4(a.x / sigma, a.y / sigma, a.z / sigma, a.w / sigma));
     }
-    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK)
+    for (int64_t i = n4 * 4 + (int64_t)bid * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)nblocks * EW_BLOCK)
         wn[i] = w[i] / sigma;
-    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * EW_BLOCK)
+    for (int64_t i = (int64_t)bid * EW_BLOCK + threadIdx.x; i < rows; i += (int64_t)nblocks * EW_BLOCK)
         v_out[i] = vraw[i] * rs_v;
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void sn_normalize_kernel(const float* __restrict__ w, const double* scr,
+                                                                 const float* vraw, float* __restrict__ wn,
+                                                                 float* v_out, int64_t n, int rows) {
+    sn_normalize_body(w, scr, vraw, wn, v_out, n, rows, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(EW_BLOCK) void sn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ u,
@@ -712,6 +745,100 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_bwd_kernel(const float* __restric
     for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK) {
         const int r = (int)(i / cols), c = (int)(i % cols);
         dw[i] = (g[i] - d * v[r] * u[c]) * inv_sigma;
+    }
+}
+
+// ---- multi-tensor form: blockIdx.y = item of a device-resident BgSnItem table ------------------
+struct SnMask { uint64_t w[4]; };
+__device__ __forceinline__ bool sn_bit(const SnMask& m, int i) { return (m.w[i >> 6] >> (i & 63)) & 1ull; }
+
+__device__ __forceinline__ double* sn_scr(const BgSnItem& it, char* ws) {
+    return reinterpret_cast<double*>(ws + it.ws_offset);
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void sn_batch_rowdot_kernel(const BgSnItem* __restrict__ items, char* ws) {
+    const BgSnItem it = items[blockIdx.y];
+    double* scr = sn_scr(it, ws);
+    float* vraw = reinterpret_cast<float*>(scr + 4 + it.cols);
+    sn_rowdot_body(it.w, it.u, vraw, scr, it.rows, it.cols, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void sn_batch_colsum_kernel(const BgSnItem* __restrict__ items, char* ws) {
+    const BgSnItem it = items[blockIdx.y];
+    double* scr = sn_scr(it, ws);
+    float* vraw = reinterpret_cast<float*>(scr + 4 + it.cols);
+    int cblocks, rpb, rchunks;
+    sn_colsum_plan(it.rows, it.cols, &cblocks, &rpb, &rchunks);
+    const int units = cblocks * rchunks;
+    for (int unit = blockIdx.x; unit < units; unit += gridDim.x)
+        sn_colsum_body(it.w, vraw, scr + 4, it.rows, it.cols, rpb, unit % cblocks, unit / cblocks);
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void sn_batch_finalize_kernel(const BgSnItem* __restrict__ items, char* ws) {
+    __shared__ float sh[4];
+    const BgSnItem it = items[blockIdx.x];
+    double* scr = sn_scr(it, ws);
+    sn_finalize_body(scr, scr + 4, it.u, it.sigma, it.cols, sh);
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void sn_batch_normalize_kernel(const BgSnItem* __restrict__ items, char* ws) {
+    const BgSnItem it = items[blockIdx.y];
+    double* scr = sn_scr(it, ws);
+    const float* vraw = reinterpret_cast<const float*>(scr + 4 + it.cols);
+    sn_normalize_body(it.w, scr, vraw, it.w_norm, it.v, (int64_t)it.rows * it.cols, it.rows, blockIdx.x, gridDim.x);
+}
+
+// dots[item] = <g_wnorm, w_norm>
+__global__ __launch_bounds__(EW_BLOCK) void sn_batch_dot_kernel(const BgSnItem* __restrict__ items, double* dots,
+                                                                 SnMask enable) {
+    __shared__ float sh[4];
+    if (!sn_bit(enable, blockIdx.y)) return;
+    const BgSnItem it = items[blockIdx.y];
+    const int64_t n = (int64_t)it.rows * it.cols;
+    const int64_t n4 = n / 4;
+    if ((int64_t)blockIdx.x * EW_BLOCK >= n4 + (n - n4 * 4)) return;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+        float4 av = ldg4(it.g_wnorm + i * 4), bv = ldg4(it.w_norm + i * 4);
+        s += av.x * bv.x + av.y * bv.y + av.z * bv.z + av.w * bv.w;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK)
+        s += it.g_wnorm[i] * it.w_norm[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) atomicAdd(&dots[blockIdx.y], (double)s);
+}
+
+// dw (+)= (g - dot * v^T u) / sigma
+__global__ __launch_bounds__(EW_BLOCK) void sn_batch_bwd_kernel(const BgSnItem* __restrict__ items, const double* dots,
+                                                                 SnMask enable, SnMask accumulate) {
+    if (!sn_bit(enable, blockIdx.y)) return;
+    const BgSnItem it = items[blockIdx.y];
+    const bool acc = sn_bit(accumulate, blockIdx.y);
+    const float inv_sigma = 1.f / *it.sigma;
+    const float d = (float)dots[blockIdx.y];
+    const int cols = it.cols;
+    const int64_t n = (int64_t)it.rows * cols;
+    if ((cols & 3) == 0) {
+        const int64_t n4 = n / 4;
+        for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+            const int64_t e = i * 4;
+            const int r = (int)(e / cols), c = (int)(e - (int64_t)r * cols);
+            const float4 g = ldg4(it.g_wnorm + e), u = ldg4(it.u + c);
+            const float dv = d * it.v[r];
+            float4 o = make_float4((g.x - dv * u.x) * inv_sigma, (g.y - dv * u.y) * inv_sigma,
+                                   (g.z - dv * u.z) * inv_sigma, (g.w - dv * u.w) * inv_sigma);
+            if (acc) {
+                const float4 p = ldg4(it.dw + e);
+                o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+            }
+            stg4(it.dw + e, o);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK) {
+            const int r = (int)(i / cols), c = (int)(i % cols);
+            const float o = (it.g_wnorm[i] - d * it.v[r] * it.u[c]) * inv_sigma;
+            it.dw[i] = acc ? it.dw[i] + o : o;
+        }
     }
 }
 
@@ -1054,6 +1181,55 @@ int bg_spectral_norm_bwd(const float* g_wnorm, const float* w_norm, const float*
     BG_LAUNCH_CHECK();
     hipLaunchKernelGGL(sn_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, g_wnorm, u_hat, v_hat, sigma, scr + 3, dw,
                        rows, cols);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+static bool sn_masks(const uint64_t* m, int n, SnMask* out, bool dflt) {
+    for (int i = 0; i < 4; ++i) out->w[i] = dflt ? ~0ull : 0ull;
+    if (m)
+        for (int i = 0; i < (n + 63) / 64; ++i) out->w[i] = m[i];
+    return true;
+}
+
+int bg_spectral_norm_batch_fwd(const BgSnItem* items_dev, int n_items, void* ws, size_t ws_bytes, void* stream) {
+    BG_REQUIRE(items_dev && n_items > 0 && ws && ws_bytes > 0, "bg_spectral_norm_batch_fwd: bad argument");
+    BG_REQUIRE(((uintptr_t)ws & 15) == 0, "bg_spectral_norm_batch_fwd: workspace must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(ws, 0, ws_bytes, s) != hipSuccess) {
+        set_error("bg_spectral_norm_batch_fwd: memset failed");
+        return BG_ERR_LAUNCH;
+    }
+    char* w8 = reinterpret_cast<char*>(ws);
+    const int GX = 128;
+    hipLaunchKernelGGL(sn_batch_rowdot_kernel, dim3(GX, n_items), dim3(EW_BLOCK), 0, s, items_dev, w8);
+    BG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sn_batch_colsum_kernel, dim3(GX, n_items), dim3(EW_BLOCK), 0, s, items_dev, w8);
+    BG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sn_batch_finalize_kernel, dim3(n_items), dim3(EW_BLOCK), 0, s, items_dev, w8);
+    BG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sn_batch_normalize_kernel, dim3(GX, n_items), dim3(EW_BLOCK), 0, s, items_dev, w8);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_spectral_norm_batch_bwd(const BgSnItem* items_dev, int n_items, const uint64_t* enable_mask,
+                               const uint64_t* accumulate_mask, void* ws, size_t ws_bytes, void* stream) {
+    BG_REQUIRE(items_dev && n_items > 0 && n_items <= 256, "bg_spectral_norm_batch_bwd: 1..256 items per call");
+    BG_REQUIRE(ws && ws_bytes >= sizeof(double) * (size_t)n_items && ((uintptr_t)ws & 7) == 0,
+               "bg_spectral_norm_batch_bwd: workspace too small");
+    hipStream_t s = as_stream(stream);
+    SnMask en, acc;
+    sn_masks(enable_mask, n_items, &en, true);
+    sn_masks(accumulate_mask, n_items, &acc, false);
+    if (hipMemsetAsync(ws, 0, sizeof(double) * (size_t)n_items, s) != hipSuccess) {
+        set_error("bg_spectral_norm_batch_bwd: memset failed");
+        return BG_ERR_LAUNCH;
+    }
+    double* dots = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(sn_batch_dot_kernel, dim3(64, n_items), dim3(EW_BLOCK), 0, s, items_dev, dots, en);
+    BG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sn_batch_bwd_kernel, dim3(128, n_items), dim3(EW_BLOCK), 0, s, items_dev, dots, en, acc);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

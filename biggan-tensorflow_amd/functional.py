@@ -312,6 +312,103 @@ class SpectralNormFn(Function):
         return dw, None
 
 
+class SnBatch:
+    """Every spectrally-normalised weight of one network in one multi-tensor call (4 launches forward,
+    2 backward) instead of a kernel chain per weight.  ``forward()`` runs the power iteration of all
+    weights (``u`` in place) and returns the normalised weights as pseudo-variables: the consumers'
+    backward kernels write dL/d(w/sigma) into a flat buffer through ``emit_grad`` and ``backward()``
+    turns all of them into dL/dw inside the parameter-gradient arena (ops.py:718-747)."""
+
+    ALIGN = 64
+
+    def __init__(self, pairs):
+        import ctypes
+        L = lib()
+        self.w = [p[0] for p in pairs]
+        self.u = [p[1] for p in pairs]
+        n = len(pairs)
+        if not 0 < n <= 256:
+            raise ValueError("SnBatch handles 1..256 weights, got %d" % n)
+        dev = self.w[0].device
+        offs, off, rows_tot, ws_off, ws_offs = [], 0, 0, 0, []
+        self.rows, self.cols = [], []
+        for w in self.w:
+            cols = w.shape[-1]
+            rows = w.numel() // cols
+            self.rows.append(rows)
+            self.cols.append(cols)
+            offs.append(off)
+            off += (w.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            ws_offs.append(ws_off)
+            ws_off += (int(L.bg_spectral_norm_workspace_bytes(rows, cols)) + 15) // 16 * 16
+            rows_tot += (rows + 3) // 4 * 4
+        self.wn_flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.gwn_flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.v_flat = torch.zeros(rows_tot, dtype=torch.float32, device=dev)
+        self.sigma = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.ws_bytes = ws_off
+        self.ws = workspace(max(ws_off, 8 * n), dev)
+        self.dots = workspace(8 * n, dev)
+        self.wn, self.v, self.dw = [], [], []
+        items = (hip.BgSnItem * n)()
+        r0 = 0
+        for i, w in enumerate(self.w):
+            wn = self.wn_flat.narrow(0, offs[i], w.numel()).view(w.shape)
+            wn.bg_name = (getattr(w, "bg_name", None) or "w%d" % i) + ":sn"
+            wn.bg_grad = self.gwn_flat.narrow(0, offs[i], w.numel()).view(w.shape)
+            wn.bg_touched = False
+            v = self.v_flat.narrow(0, r0, self.rows[i])
+            r0 += (self.rows[i] + 3) // 4 * 4
+            dw = getattr(w, "bg_grad", None)
+            if dw is None:
+                dw = torch.zeros_like(w)
+                w.bg_grad = dw
+                w.bg_touched = False
+            self.wn.append(wn)
+            self.v.append(v)
+            self.dw.append(dw)
+            it = items[i]
+            it.w, it.u, it.v = w.data_ptr(), self.u[i].data_ptr(), v.data_ptr()
+            it.sigma = self.sigma.data_ptr() + 4 * i
+            it.w_norm, it.g_wnorm, it.dw = wn.data_ptr(), wn.bg_grad.data_ptr(), dw.data_ptr()
+            it.ws_offset, it.rows, it.cols = ws_offs[i], self.rows[i], self.cols[i]
+            for t in (w, self.u[i], dw):
+                if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                    raise RuntimeError("SnBatch needs contiguous CUDA fp32 tensors")
+        raw = bytes(items)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.n = n
+        self._ctypes = ctypes
+
+    def forward(self):
+        check(lib().bg_spectral_norm_batch_fwd(hip.ptr(self.table), self.n, hip.ptr(self.ws), self.ws_bytes, stream()))
+        for w, wn in zip(self.w, self.wn):
+            wn.requires_grad_(bool(w.requires_grad))
+            wn.bg_touched = False
+        return self.wn
+
+    def backward(self):
+        """dL/dw (+)= SN-backward of every normalised weight that received a gradient this step."""
+        words = (self.n + 63) // 64
+        en = [0] * words
+        acc = [0] * words
+        any_ = False
+        for i, (w, wn) in enumerate(zip(self.w, self.wn)):
+            if wn.bg_touched and w.requires_grad:
+                en[i >> 6] |= 1 << (i & 63)
+                any_ = True
+                if w.bg_touched:
+                    acc[i >> 6] |= 1 << (i & 63)
+                w.bg_touched = True
+            wn.bg_touched = False
+        if not any_:
+            return
+        c = self._ctypes
+        arr = c.c_uint64 * words
+        check(lib().bg_spectral_norm_batch_bwd(hip.ptr(self.table), self.n, arr(*en), arr(*acc), hip.ptr(self.dots),
+                                               8 * self.n, stream()))
+
+
 # ------------------------------------------------------------------------------------------
 # batch norm (+ PReLU)
 # ------------------------------------------------------------------------------------------

@@ -28,6 +28,11 @@ class BgGemmDesc(Structure):
                 ("strideA", c_int64), ("strideB", c_int64), ("strideC", c_int64)]
 
 
+class BgSnItem(Structure):
+    _fields_ = [("w", c_void_p), ("u", c_void_p), ("v", c_void_p), ("sigma", c_void_p), ("w_norm", c_void_p),
+                ("g_wnorm", c_void_p), ("dw", c_void_p), ("ws_offset", c_int64), ("rows", c_int32), ("cols", c_int32)]
+
+
 _P = c_void_p
 _CD = POINTER(BgConvDesc)
 _GD = POINTER(BgGemmDesc)
@@ -61,6 +66,8 @@ SIGNATURES = {
     "bg_spectral_norm_workspace_bytes": (c_size_t, [c_int, c_int]),
     "bg_spectral_norm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
     "bg_spectral_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
+    "bg_spectral_norm_batch_fwd": (c_int, [_P, c_int, _P, c_size_t, _P]),
+    "bg_spectral_norm_batch_bwd": (c_int, [_P, c_int, _P, _P, _P, c_size_t, _P]),
     "bg_bn_stats": (c_int, [_P, _P, c_int64, c_int, _P]),
     "bg_bn_finalize": (c_int, [_P, c_double, c_float, c_float, c_int, _P, _P, _P, _P, c_int, _P]),
     "bg_bn_apply_act_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),

@@ -15,6 +15,7 @@ import time
 import torch
 
 from . import ops
+from . import functional as Fn
 from . import scope as S
 from . import hip
 from .ops import (fully_connected, resblock_up_condition, resblock_down, resblock, self_attention_2, conv, bn,
@@ -217,6 +218,7 @@ class BigGAN(GANBase):
             opt["conv"]["regularizer"] = None
             opt["fc_regularizer"] = None
 
+        self._sn_prefetch("generator", z)
         with S.variable_scope("generator", reuse=reuse):
             block_info = self.g_block_info()
             split_sizes = self.z_split_sizes()
@@ -285,6 +287,7 @@ class BigGAN(GANBase):
                "downsampling_method": self.downsampling_method, "self_attention_bias": self.bias_in_sa,
                "bn": copy.deepcopy(self.bn_options), "conv": copy.deepcopy(self.conv_options)}
         outputs = {}
+        self._sn_prefetch("discriminator", x)
         with S.variable_scope("discriminator", reuse=reuse):
             ch = self.d_channels_for_block(0)
             block_info = self.d_block_info()
@@ -327,9 +330,25 @@ class BigGAN(GANBase):
         self.d_arena = self.store.arenas["discriminator"]
         self.d_vars = self.store.trainable_variables('discriminator')                  # BigGAN.py:915-917
         self.g_vars = self.store.trainable_variables('generator')
+        self.sn_batches = {}
+        if self.store.device.type == "cuda":
+            for group in ("generator", "discriminator"):
+                pairs = [(self.store.vars[w], self.store.vars[u]) for w, u in self.store.sn_pairs.items()
+                         if w.startswith(group + "/") and w in self.store.arenas[group].offsets]
+                for i in range(0, len(pairs), 256):
+                    self.sn_batches.setdefault(group, []).append(Fn.SnBatch(pairs[i:i + 256]))
         self.counter = 0
         self.built = True
         return self
+
+    def _sn_prefetch(self, group, x):
+        if x.is_cuda:
+            for b in getattr(self, "sn_batches", {}).get(group, ()):
+                ops.sn_prefetch(b)
+
+    def _sn_backward(self, group):
+        for b in getattr(self, "sn_batches", {}).get(group, ()):
+            b.backward()
 
     # ---- data-parallel hooks -----------------------------------------------------------------
     def _reduce_fn(self):
@@ -388,6 +407,7 @@ class BigGAN(GANBase):
         out = self.d_forward(real, z, draws_real, draws_fake)
         self.store.begin_backward("discriminator")
         out["d_loss"].backward()
+        self._sn_backward("discriminator")
         self.store.zero_untouched("discriminator")
         self._allreduce_grads(self.d_arena)
         if apply:
@@ -419,6 +439,7 @@ class BigGAN(GANBase):
             torch.autograd.backward(roots, [ones] + [rw] * len(out["regs"]))
         finally:
             self._set_requires_grad(self.d_vars, True)
+        self._sn_backward("generator")
         self.store.zero_untouched("generator")
         self._allreduce_grads(self.g_arena)
         if apply:

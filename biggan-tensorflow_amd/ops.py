@@ -44,6 +44,16 @@ def begin_run(reduce_fn=None, world=1):
     _run.world = world
 
 
+def sn_prefetch(batch):
+    """Run the power iteration of every spectrally-normalised weight of a network in one multi-tensor
+    call (functional.SnBatch) and put the results where ``spectral_norm`` looks first."""
+    if batch is None:
+        return
+    needs_base = torch.is_grad_enabled()
+    for w, wn in zip(batch.w, batch.forward()):
+        _run.sn_cache[w.bg_name] = (wn, needs_base and w.requires_grad)
+
+
 def get_regularization_losses():
     return list(_run.reg_losses)
 
@@ -546,9 +556,11 @@ def spectral_norm(w, iteration=1, _shape_only=False):
     if iteration != 1:
         raise NotImplementedError("spectral_norm iteration != 1")
     u = get_variable("u", [1, w.shape[-1]], initializer=S.random_normal_initializer(), trainable=False)
+    key = getattr(w, "bg_name", None)
+    if key is not None:
+        S.default_store().register_sn(key, u.bg_name)
     if _shape_only:
         return w          # shape-propagation (manifest) mode: only the variable is registered
-    key = getattr(w, "bg_name", None)
     if key is not None and key in _run.sn_cache:
         cached, needs = _run.sn_cache[key]
         if needs == (torch.is_grad_enabled() and w.requires_grad):

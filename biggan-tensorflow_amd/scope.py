@@ -90,6 +90,10 @@ class VariableStore:
         self._stack = []                     # [(full_name, reuse)]
         self._counts = {}                    # scope path -> times opened (for default_name uniquifying)
         self.frozen = False
+        self.sn_pairs = OrderedDict()        # spectrally-normalised weight name -> name of its u vector
+
+    def register_sn(self, w_name, u_name):
+        self.sn_pairs.setdefault(w_name, u_name)
 
     # ---- scope handling -------------------------------------------------------------------
     @property

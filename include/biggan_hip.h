@@ -129,6 +129,27 @@ int bg_spectral_norm_bwd(const float* g_wnorm, const float* w_norm, const float*
                          const float* v_hat, const float* sigma, float* dw, int rows, int cols,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* Multi-tensor form: every spectrally-normalised weight of one network in 4 (fwd) / 2 (bwd) launches.
+ * The BgSnItem table lives in device memory (pointers are stable: flat arenas); ws_offset is the byte
+ * offset (16-byte aligned) of the item's scratch of bg_spectral_norm_workspace_bytes(rows, cols) bytes
+ * inside ws; fwd zeroes ws[0, ws_bytes).  u is updated in place.  bwd: bit i of enable_mask /
+ * accumulate_mask (host arrays of ceil(n/64) words; NULL = all / none) selects whether item i is
+ * processed and whether dw is added to instead of overwritten; ws >= 8 * n_items bytes. */
+typedef struct BgSnItem {
+    const float* w;        /* [rows, cols] */
+    float* u;              /* [cols], in/out */
+    float* v;              /* [rows], out */
+    float* sigma;          /* [1], out */
+    float* w_norm;         /* [rows, cols], out */
+    const float* g_wnorm;  /* bwd in: dL/d(w_norm) */
+    float* dw;             /* bwd out: dL/dw */
+    int64_t ws_offset;
+    int32_t rows, cols;
+} BgSnItem;
+int bg_spectral_norm_batch_fwd(const BgSnItem* items_dev, int n_items, void* ws, size_t ws_bytes, void* stream);
+int bg_spectral_norm_batch_bwd(const BgSnItem* items_dev, int n_items, const uint64_t* enable_mask,
+                               const uint64_t* accumulate_mask, void* ws, size_t ws_bytes, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Batch statistics + (conditional) batch-norm + PReLU (ops.py:532-537, 580-585, 611-643).
  *   x [N,HW,C].  stats: sums[0:C] = sum x, sums[C:2C] = sum x^2 over N*HW (fp64 accumulators, so the

@@ -266,6 +266,62 @@ def test_spectral_norm_fwd_bwd(shape):
     assert rel_err(t2n(wc.grad).reshape(-1, cols), exp.numpy()) < 5e-5
 
 
+def test_spectral_norm_multi_tensor_batch():
+    """functional.SnBatch: all weights of a network in one call; bwd with skip / overwrite / accumulate."""
+    Fn = _fn()
+    shapes = [(3, 3, 16, 32), (32, 64), (4, 4, 8, 24), (184, 1024), (3, 3, 8, 3), (16, 1), (1, 1, 64, 8),
+              (3, 3, 256, 256), (20, 2050)]
+    rng = np.random.default_rng(77)
+    ws = [rng.standard_normal(s) * 0.1 for s in shapes]
+    us = [rng.standard_normal((1, s[-1])) for s in shapes]
+    wc = [cu(w, True) for w in ws]
+    uc = [cu(u) for u in us]
+    batch = Fn.SnBatch(list(zip(wc, uc)))
+    wns = batch.forward()
+    Gs = [rng.standard_normal(s) for s in shapes]
+    prior = [rng.standard_normal(s) for s in shapes]
+    exp_dw = []
+    for i, (w, u) in enumerate(zip(ws, us)):
+        cols = w.shape[-1]
+        W = torch.tensor(w).reshape(-1, cols)
+        v_hat = R.l2_normalize(torch.tensor(u) @ W.t())
+        u_hat = R.l2_normalize(v_hat @ W)
+        sigma = (v_hat @ W @ u_hat.t()).item()
+        assert rel_err(t2n(wns[i]), w / sigma) < TOL, shapes[i]
+        assert rel_err(t2n(uc[i]), u_hat.numpy()) < TOL, shapes[i]
+        assert rel_err(t2n(batch.v[i]), v_hat.numpy().ravel()) < TOL, shapes[i]
+        assert abs(batch.sigma[i].item() - sigma) < 1e-5 * abs(sigma)
+        Gm = torch.tensor(Gs[i]).reshape(-1, cols)
+        exp_dw.append(((Gm - (Gm * (W / sigma)).sum() * (v_hat.t() @ u_hat)) / sigma).numpy().reshape(w.shape))
+    # item 1: no gradient arrives (skipped, slot untouched); item 2: slot already holds a gradient (accumulate)
+    for i, wn in enumerate(wns):
+        assert wn.requires_grad
+        wc[i].bg_grad.copy_(cu(prior[i]))
+        if i == 1:
+            continue
+        Fn.emit_grad(wn, lambda out, i=i: out.copy_(cu(Gs[i])))
+        wc[i].bg_touched = (i == 2)
+    batch.backward()
+    for i in range(len(shapes)):
+        got = t2n(wc[i].bg_grad)
+        if i == 1:
+            assert np.array_equal(got, prior[i].astype(np.float32)) and not wc[i].bg_touched
+        elif i == 2:
+            assert rel_err(got, exp_dw[i] + prior[i]) < 5e-5
+        else:
+            assert rel_err(got, exp_dw[i]) < 5e-5, shapes[i]
+            assert wc[i].bg_touched
+    # second forward continues the power iteration from the updated u
+    wns = batch.forward()
+    W = torch.tensor(ws[3]).reshape(-1, shapes[3][-1])
+    u1 = torch.tensor(t2n(uc[3]).astype(np.float64))
+    v_hat = R.l2_normalize(torch.tensor(us[3]) @ W.t())
+    u_hat = R.l2_normalize(v_hat @ W)
+    v2 = R.l2_normalize(u_hat @ W.t())
+    u2 = R.l2_normalize(v2 @ W)
+    assert rel_err(t2n(uc[3]), u2.numpy()) < TOL and u1 is not None
+
+
 # ------------------------------------------------------------------------------------------
 # batch norm + PReLU (ops.py:532-537, 580-585, 611-643)
 # ------------------------------------------------------------------------------------------
