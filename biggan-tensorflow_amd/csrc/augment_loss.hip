@@ -232,6 +232,27 @@ __global__ __launch_bounds__(AL_BLOCK) void hinge_g_grad_kernel(const float* sum
 }
 
 // ------------------------------------------------------------------------------------------
+// class-label loss (utils.py:366-369): scale * sum(sigmoid_cross_entropy_with_logits(t, x) * w[j])
+//   ce = max(x,0) - x t + log1p(exp(-|x|)) ; d/dx = sigmoid(x) - t.   Single block: the sum is deterministic.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AL_BLOCK) void sigmoid_ce_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                               const float* __restrict__ w, float scale,
+                                                               float* loss_out, float* __restrict__ dx, int B, int n) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    const int total = B * n;
+    for (int i = threadIdx.x; i < total; i += AL_BLOCK) {
+        const float xi = x[i], ti = t[i], wi = w ? w[i % n] : 1.f;
+        const float e = __expf(-fabsf(xi));
+        acc += (fmaxf(xi, 0.f) - xi * ti + log1pf(e)) * wi;
+        const float sig = xi >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        dx[i] = (sig - ti) * wi * scale;
+    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) *loss_out = acc * scale;
+}
+
+// ------------------------------------------------------------------------------------------
 // ortho-cosine regulariser on the Gram matrix A [c,c]: one block per row
 //   Ahat = l2n_rows(A); R[i,j] = (sum_k Ahat[i,k] - Ahat[i,j]) / sqrt(c-1); loss += scale/2 sum R^2
 //   dR = scale R ; dAhat[i,j] = (sum_j' dR[i,j'] - dR[i,j]) / sqrt(c-1) ;
@@ -429,6 +450,15 @@ int bg_hinge_g_grad(const float* sums, double n_global, float flood, float* d_fa
     BG_REQUIRE(sums && d_fake && n > 0 && n_global > 0, "bg_hinge_g_grad: bad argument");
     hipLaunchKernelGGL(hinge_g_grad_kernel, dim3((n + AL_BLOCK - 1) / AL_BLOCK), dim3(AL_BLOCK), 0, as_stream(stream),
                        sums, n_global, flood, d_fake, loss_out, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_sigmoid_ce(const float* logits, const float* truth, const float* weights, float scale, float* loss_out,
+                  float* dlogits, int B, int n, void* stream) {
+    BG_REQUIRE(logits && truth && loss_out && dlogits && B > 0 && n > 0, "bg_sigmoid_ce: bad argument");
+    hipLaunchKernelGGL(sigmoid_ce_kernel, dim3(1), dim3(AL_BLOCK), 0, as_stream(stream), logits, truth, weights, scale,
+                       loss_out, dlogits, B, n);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -755,6 +755,32 @@ class HingeGLossFn(Function):
         return df, None, None, None
 
 
+class SigmoidCeLossFn(Function):
+    """cls_loss_fn('logistic', w)(truth, answer) * loss_weight (utils.py:366-369, BigGAN.py:853,894):
+    mean over the GLOBAL batch x labels of the weighted sigmoid cross-entropy."""
+
+    @staticmethod
+    def forward(ctx, truth, logits, weights, loss_weight, reduce_fn, world):
+        truth, logits = _c(truth), _c(logits)
+        B, n = logits.shape
+        dev = logits.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dl = torch.empty_like(logits)
+        check(lib().bg_sigmoid_ce(f32(logits), f32(truth), f32(weights), float(loss_weight) / float(B * world * n),
+                                  f32(loss), f32(dl), B, n, stream()))
+        if reduce_fn is not None:
+            reduce_fn(loss)
+        ctx.dl = dl
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        out = torch.empty_like(ctx.dl)
+        check(lib().bg_scale_dev(f32(ctx.dl), f32(g), f32(out), out.numel(), stream()))
+        return None, out, None, None, None, None
+
+
 class OrthoCosineRegFn(Function):
     """orthogonal_regularizer(scale, 'ortho_cosine')(w) (utils.py:180-235): scale * l2_loss(R).
     The weight gradient dW = W (dA + dA^T) is produced in backward."""

@@ -21,7 +21,7 @@ from . import hip
 from .ops import (fully_connected, resblock_up_condition, resblock_down, resblock, self_attention_2, conv, bn,
                   prelu, relu, lrelu, tanh, global_sum_pooling, discriminator_loss, generator_loss)
 from .DiffAugment import DiffAugment, draw as draw_augment
-from .utils import orthogonal_regularizer, orthogonal_regularizer_fc, round_up
+from .utils import orthogonal_regularizer, orthogonal_regularizer_fc, round_up, cls_loss_fn
 
 
 class GANBase(object):
@@ -58,7 +58,7 @@ class BigGAN(GANBase):
         self.depth = args.img_size.bit_length() - 2                                   # BigGAN.py:19
 
         unsupported = [
-            ("deep", args.deep), ("n_labels>0", args.n_labels > 0), ("cls_embedding", args.cls_embedding),
+            ("deep", args.deep), ("cls_embedding", args.cls_embedding), ("d_cls_dense_layers", args.d_cls_dense_layers),
             ("shared_z", args.shared_z > 0), ("g_z_dense_concat", args.g_z_dense_concat),
             ("g_other_level_dense_layer", args.g_other_level_dense_layer),
             ("g_no_last_resblock", args.g_no_last_resblock), ("g_mixed_resblocks", args.g_mixed_resblocks),
@@ -66,7 +66,7 @@ class BigGAN(GANBase):
             ("z_reconstruct", args.z_reconstruct), ("d_reconstruction", args.d_reconstruction),
             ("d_reconstruction_halfres", args.d_reconstruction_halfres),
             ("d_reconstruction_texture", args.d_reconstruction_texture), ("d_final_conv", args.d_final_conv),
-            ("bn_in_d", args.bn_in_d), ("c_dim!=3", args.c_dim != 3), ("virtual_batches>1", args.virtual_batches > 1),
+            ("bn_in_d", args.bn_in_d), ("c_dim!=3", args.c_dim != 3),
             ("not g_first_level_dense_layer", not args.g_first_level_dense_layer),
         ]
         bad = [n for n, v in unsupported if v]
@@ -117,6 +117,21 @@ class BigGAN(GANBase):
         self.moving_decay = args.moving_decay
         self.d_compat_use_sn_in_critic_output = args.d_compat_use_sn_in_critic_output
         self.extension_32 = getattr(args, "extension_32", False)
+        self.n_labels = args.n_labels                                                  # BigGAN.py:22-23
+        self.acgan = self.n_labels > 0
+        self.virtual_batches = max(int(args.virtual_batches), 1)
+        if self.acgan:                                                                 # BigGAN.py:91-100
+            self.cls_loss_type = args.cls_loss_type
+            self.d_cls_loss_weight = args.d_cls_loss_weight
+            self.g_cls_loss_weight = args.g_cls_loss_weight
+            self.d_compat_use_sn_in_classification = args.d_compat_use_sn_in_classification
+            if args.cls_loss_weights != '':
+                self.cls_loss_weights = list(map(float, open(args.cls_loss_weights).read().split()))
+                if len(self.cls_loss_weights) != self.n_labels:
+                    raise ValueError('Number of class loss weights does not match n_labels (' +
+                                     str(len(self.cls_loss_weights)) + " vs. " + str(self.n_labels) + ")")
+            else:
+                self.cls_loss_weights = [1.0] * self.n_labels
 
         self.store = store if store is not None else S.VariableStore(self.device, seed)
         S.set_default_store(self.store)
@@ -224,6 +239,15 @@ class BigGAN(GANBase):
             split_sizes = self.z_split_sizes()
             z2 = z.reshape(z.shape[0], -1)
             z_split = list(torch.split(z2, split_sizes, dim=-1))                       # BigGAN.py:335 (views)
+            clsz_size = 0
+            if self.acgan:                                                             # BigGAN.py:346-365
+                clsz_size = self.n_labels
+                if z.device.type == "meta":
+                    z_split = [torch.empty(zz.shape[0], zz.shape[1] + clsz_size, device="meta") for zz in z_split]
+                else:
+                    cz = cls_z.reshape(-1, clsz_size)
+                    z_split = [torch.cat([zz, cz], dim=-1) for zz in z_split]
+                split_sizes = [sz + clsz_size for sz in split_sizes]
             next_zi = [0]
 
             def next_z_split():
@@ -236,7 +260,7 @@ class BigGAN(GANBase):
             ch = self.g_channels_for_block(0, len(counts))
 
             layer_z, z_dim = next_z_split()
-            f_width = self.round_up((z_dim + 0) * 1.85, 8)                             # BigGAN.py:433
+            f_width = self.round_up(z_dim * 1.85, 8)                                   # BigGAN.py:433 (z_dim includes the labels)
             if self.activation_fn is relu:                                             # BigGAN.py:434-438
                 x = fully_connected(layer_z, units=f_width, scope='dense1', opt=opt)
                 x = relu(x)
@@ -311,6 +335,9 @@ class BigGAN(GANBase):
             critic_opt = self.make_opt_with_sn(opt, self.d_compat_use_sn_in_critic_output)
             x = fully_connected(features, units=1, opt=critic_opt, scope='D_logit')    # BigGAN.py:681-682
             outputs["real"] = x
+            if self.acgan:                                                             # BigGAN.py:686-701
+                cls_opt = self.make_opt_with_sn(opt, self.d_compat_use_sn_in_classification)
+                outputs["cls"] = fully_connected(features, units=self.n_labels, opt=cls_opt, scope='DC_logit')
             return outputs
 
     ##################################################################################
@@ -365,13 +392,14 @@ class BigGAN(GANBase):
             from .parallel import allreduce_flat
             allreduce_flat(arena.grads, self.pg)
 
-    def _adam(self, arena, lr, with_ema):
+    def _adam(self, arena, lr, with_ema, grad_scale=1.0):
         arena.step += 1
         t = arena.step
         lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)        # tf.train.AdamOptimizer
         hip.check(hip.lib().bg_adam_tf_ema_step(
             hip.f32(arena.params), hip.f32(arena.grads), hip.f32(arena.m), hip.f32(arena.v),
-            hip.f32(arena.ema) if with_ema else None, lr_t, self.beta1, self.beta2, 1e-8, self.moving_decay, 1.0,
+            hip.f32(arena.ema) if with_ema else None, lr_t, self.beta1, self.beta2, 1e-8, self.moving_decay,
+            float(grad_scale),
             arena.size, hip.stream()))
 
     def sample_z(self, B):
@@ -387,81 +415,151 @@ class BigGAN(GANBase):
             v.requires_grad_(flag)
 
     # ---- the two train ops -------------------------------------------------------------------------
-    def d_forward(self, real, z=None, draws_real=None, draws_fake=None):
-        """BigGAN.py:806-808, 856-883: D(aug(real)), D(aug(G(z))), hinge + flood.  G runs without a
-        backward graph (d_loss is minimised over d_vars only); real and fake go through D as one batch."""
+    def _cls_loss(self):
+        if getattr(self, "_cls_loss_fn", None) is None:
+            w = torch.tensor(self.cls_loss_weights, dtype=torch.float32, device=self.device)
+            self._cls_loss_fn = cls_loss_fn(self.cls_loss_type, w)                     # BigGAN.py:851-852
+        return self._cls_loss_fn
+
+    def d_forward(self, real, z=None, draws_real=None, draws_fake=None, labels=None, cls_z=None):
+        """BigGAN.py:806-808, 856-883: D(aug(real)), D(aug(G(z))), hinge + flood (+ the label loss on the
+        real half when n_labels > 0, BigGAN.py:853).  G runs without a backward graph (d_loss is minimised
+        over d_vars only); real and fake go through D as one batch."""
         B = real.shape[0]
         ops.begin_run(self._reduce_fn(), self.world)
         if z is None:
             z = self.sample_z(B)
+        if self.acgan and cls_z is None:
+            cls_z = self.synthetic_labels(B)                                           # rnd_cls_feed_dict, BigGAN.py:1454
         with torch.no_grad():
-            fake = self.generator(z, None, is_training=True)
+            fake = self.generator(z, cls_z, is_training=True)
         real_aug = DiffAugment(real, policy=self.da_policy, draws=draws_real, generator=self.gen)
         fake_aug = DiffAugment(fake, policy=self.da_policy, draws=draws_fake, generator=self.gen)
-        logits = self.discriminator(torch.cat([real_aug, fake_aug], dim=0))["real"]
+        d_out = self.discriminator(torch.cat([real_aug, fake_aug], dim=0))
+        logits = d_out["real"]
         real_logits, fake_logits = logits[:B], logits[B:]
         d_loss = discriminator_loss(self.d_loss_func, real=real_logits, fake=fake_logits, flood_level=self.d_flood)
-        return {"d_loss": d_loss, "real_logits": real_logits, "fake_logits": fake_logits, "fake": fake}
+        out = {"real_logits": real_logits, "fake_logits": fake_logits, "fake": fake}
+        if self.acgan:
+            if labels is None:
+                raise ValueError("n_labels > 0: d_forward needs the labels of the real batch")
+            real_cls = d_out["cls"][:B]
+            d_cls = self._cls_loss()(labels, real_cls, self.d_cls_loss_weight, self._reduce_fn(), self.world)
+            out["d_cls_loss"] = d_cls
+            d_loss = Fn.AddFn.apply(d_loss, d_cls)
+        out["d_loss"] = d_loss
+        return out
 
-    def d_step(self, real, z=None, draws_real=None, draws_fake=None, apply=True):
-        out = self.d_forward(real, z, draws_real, draws_fake)
+    def _per_virtual_batch(self, k, v):
+        if isinstance(v, (list, tuple)):
+            if len(v) != self.virtual_batches:
+                raise ValueError("expected %d virtual batches, got %d" % (self.virtual_batches, len(v)))
+            return v[k]
+        return v
+
+    def d_step(self, real, z=None, draws_real=None, draws_fake=None, apply=True, labels=None, cls_z=None):
+        """One run of d_ops (utils.py:252-320): with --virtual_batches k, gradients of k forward/backward
+        passes (each on its own real batch / z / draws; lists of k are accepted) are accumulated and
+        applied once, scaled 1/k; reported losses are means over the k passes."""
+        vb = self.virtual_batches
         self.store.begin_backward("discriminator")
-        out["d_loss"].backward()
-        self._sn_backward("discriminator")
+        outs = []
+        for k in range(vb):
+            out = self.d_forward(*[self._per_virtual_batch(k, a) for a in (real, z, draws_real, draws_fake, labels)],
+                                 cls_z=cls_z)                                        # one feed_dict for all k
+            out["d_loss"].backward()
+            self._sn_backward("discriminator")
+            outs.append(out)
         self.store.zero_untouched("discriminator")
         self._allreduce_grads(self.d_arena)
         if apply:
-            self._adam(self.d_arena, self.d_learning_rate, with_ema=False)
+            self._adam(self.d_arena, self.d_learning_rate, with_ema=False, grad_scale=1.0 / vb)
+        return self._mean_losses(outs, ("d_loss", "d_cls_loss"))
+
+    def _mean_losses(self, outs, keys):
+        out = outs[-1]
+        if len(outs) > 1:
+            for key in keys:
+                if key in out and out[key] is not None:
+                    acc = outs[0][key].detach().clone()
+                    for o in outs[1:]:
+                        Fn.axpby(o[key].detach(), 1.0, acc, 1.0)
+                    out[key] = Fn.axpby(acc, 0.0, acc, 1.0 / len(outs))
         return out
 
-    def g_forward(self, B, z=None, draws_fake=None):
-        """BigGAN.py:896-898: -mean(D(aug(G(z)))) + flood + regularisation losses."""
+    def g_forward(self, B, z=None, draws_fake=None, cls_z=None):
+        """BigGAN.py:896-898: -mean(D(aug(G(z)))) + flood (+ label loss, BigGAN.py:894) + regularisation losses."""
         ops.begin_run(self._reduce_fn(), self.world)
         if z is None:
             z = self.sample_z(B)
-        fake = self.generator(z, None, is_training=True)
+        if self.acgan and cls_z is None:
+            cls_z = self.synthetic_labels(B)
+        fake = self.generator(z, cls_z, is_training=True)
         fake_aug = DiffAugment(fake, policy=self.da_policy, draws=draws_fake, generator=self.gen)
-        fake_logits = self.discriminator(fake_aug)["real"]
+        d_out = self.discriminator(fake_aug)
+        fake_logits = d_out["real"]
         g_adv = generator_loss(self.gan_type, fake=fake_logits, real=None, flood_level=self.g_flood)
-        regs = ops.get_regularization_losses() if self.g_regularization_method != 'none' else []
-        return {"g_adv": g_adv, "regs": regs, "fake_logits": fake_logits, "fake": fake}
+        out = {"fake_logits": fake_logits, "fake": fake}
+        if self.acgan:
+            g_cls = self._cls_loss()(cls_z, d_out["cls"], self.g_cls_loss_weight, self._reduce_fn(), self.world)
+            out["g_cls_loss"] = g_cls
+            g_adv = Fn.AddFn.apply(g_adv, g_cls)
+        out["g_adv"] = g_adv
+        out["regs"] = ops.get_regularization_losses() if self.g_regularization_method != 'none' else []
+        return out
 
-    def g_step(self, B, z=None, draws_fake=None, apply=True):
+    def g_step(self, B, z=None, draws_fake=None, apply=True, cls_z=None):
+        vb = self.virtual_batches
         self._set_requires_grad(self.d_vars, False)        # g_loss is minimised over g_vars only
+        outs = []
         try:
-            out = self.g_forward(B, z, draws_fake)
             self.store.begin_backward("generator")
-            roots = [out["g_adv"]] + out["regs"]
-            ones = torch.ones(1, dtype=torch.float32, device=self.device)
-            # regularisation terms are replicated on every rank: weight them 1/world so that the
-            # SUM all-reduce of the flat gradient arena yields the single-process gradient
-            rw = ones if self.world == 1 else ones / self.world
-            torch.autograd.backward(roots, [ones] + [rw] * len(out["regs"]))
+            for k in range(vb):
+                out = self.g_forward(B, self._per_virtual_batch(k, z), self._per_virtual_batch(k, draws_fake), cls_z)
+                roots = [out["g_adv"]] + out["regs"]
+                ones = torch.ones(1, dtype=torch.float32, device=self.device)
+                # regularisation terms are replicated on every rank: weight them 1/world so that the
+                # SUM all-reduce of the flat gradient arena yields the single-process gradient
+                rw = ones if self.world == 1 else ones / self.world
+                torch.autograd.backward(roots, [ones] + [rw] * len(out["regs"]))
+                self._sn_backward("generator")
+                if out["regs"]:
+                    out["g_reg"] = torch.stack([r.detach() for r in out["regs"]]).sum()
+                    out["g_loss"] = out["g_adv"].detach() + out["g_reg"]
+                else:
+                    out["g_reg"] = torch.zeros(1, device=self.device)
+                    out["g_loss"] = out["g_adv"].detach()
+                outs.append(out)
         finally:
             self._set_requires_grad(self.d_vars, True)
-        self._sn_backward("generator")
         self.store.zero_untouched("generator")
         self._allreduce_grads(self.g_arena)
         if apply:
-            self._adam(self.g_arena, self.g_learning_rate, with_ema=True)
-        if out["regs"]:
-            out["g_reg"] = torch.stack([r.detach() for r in out["regs"]]).sum()
-            out["g_loss"] = out["g_adv"].detach() + out["g_reg"]
-        else:
-            out["g_reg"] = torch.zeros(1, device=self.device)
-            out["g_loss"] = out["g_adv"].detach()
-        return out
+            self._adam(self.g_arena, self.g_learning_rate, with_ema=True, grad_scale=1.0 / vb)
+        return self._mean_losses(outs, ("g_adv", "g_reg", "g_loss", "g_cls_loss"))
 
-    def train_step(self, real):
-        """One iteration of BigGAN.py:1061-1084."""
+    def train_step(self, real, labels=None):
+        """One iteration of BigGAN.py:1061-1084.  ``real`` (and ``labels`` when n_labels > 0) may be lists
+        of --virtual_batches tensors."""
         losses = {}
-        d = self.d_step(real)
+        first = real[0] if isinstance(real, (list, tuple)) else real
+        if self.acgan and labels is None:
+            labels = [self.synthetic_labels(first.shape[0]) for _ in range(self.virtual_batches)]
+        d = self.d_step(real, labels=labels)
         losses["d_loss"] = d["d_loss"]
         if (self.counter - 1) % self.n_critic == 0:                                    # BigGAN.py:1080
-            g = self.g_step(real.shape[0])
+            g = self.g_step(first.shape[0])
             losses["g_loss"] = g["g_loss"]
         self.counter += 1
         return losses
+
+    def synthetic_labels(self, B):
+        """Synthetic one-hot labels, uniform classes (the reference draws tags from its label file,
+        BigGAN.py:1446-1455)."""
+        idx = torch.randint(0, self.n_labels, (B,), device=self.device, generator=self.gen)
+        lab = torch.zeros(B, self.n_labels, dtype=torch.float32, device=self.device)
+        lab[torch.arange(B, device=self.device), idx] = 1.0
+        return lab
 
     def synthetic_batch(self, B=None):
         """Synthetic images U(-1,1) [B,S,S,c_dim] on the device (the reference reads PNG files)."""

@@ -51,6 +51,24 @@ def orthogonal_regularizer_fc(scale, type='ortho'):
     return orthogonal_regularizer(scale, type)
 
 
+##################################################################################
+# Class-label loss (utils.py:323-377)
+##################################################################################
+def cls_loss_fn(type, cls_weights):
+    """utils.py:366-369: loss(truth, answer) = mean(sigmoid_cross_entropy_with_logits(truth, answer) * w).
+    ``cls_weights`` is a device tensor [n_labels] (or None = ones).  The returned callable takes an
+    optional ``loss_weight`` folded into the kernel (BigGAN.py:853,894)."""
+    if type != 'logistic':
+        if type == 'euclidean' or '-' in str(type):
+            raise NotImplementedError("cls_loss_type '%s' is outside the hot path (only 'logistic')" % type)
+        raise ValueError("Invalid label loss type: " + str(type))
+
+    def loss(truth, answer, loss_weight=1.0, reduce_fn=None, world=1):
+        from . import functional as Fn
+        return Fn.SigmoidCeLossFn.apply(truth, answer, cls_weights, loss_weight, reduce_fn, world)
+    return loss
+
+
 def add_n(tensors):
     """tf.add_n over 1-element device tensors (loss bookkeeping, BigGAN.py:898)."""
     out = tensors[0]

@@ -240,6 +240,13 @@ int bg_hinge_g_sums(const float* fake, float* sums, int n, void* stream);
 int bg_hinge_g_grad(const float* sums, double n_global, float flood, float* d_fake, float* loss_out,
                     int n, void* stream);
 
+/* Class-label loss of the conditional model (utils.py:366-369, BigGAN.py:853,894), 'logistic' type:
+ *   loss = scale * sum_{b,j} sigmoid_cross_entropy_with_logits(truth, logits)[b,j] * weights[j]
+ *   dlogits = scale * weights[j] * (sigmoid(logits) - truth);  scale = loss_weight / (global_batch * n).
+ *   weights may be NULL (all ones).  logits/truth/dlogits are [B, n]. */
+int bg_sigmoid_ce(const float* logits, const float* truth, const float* weights, float scale, float* loss_out,
+                  float* dlogits, int B, int n, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Orthogonal-cosine regulariser (utils.py:180-235) from the Gram matrix A = W^T W [c,c]
  * (computed with bg_gemm), using R[i,j] = (sum_k Ahat[i,k] - Ahat[i,j]) / sqrt(c-1):

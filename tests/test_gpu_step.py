@@ -90,32 +90,43 @@ def _run_parity(tr, gan, batch, check_state=True):
     a_r, a_fd, a_fg = dev_draws(batch["aug_real"]), dev_draws(batch["aug_fake_d"]), dev_draws(batch["aug_fake_g"])
     state0 = tr.vs.export()
     hip0 = gan.store.export_arrays()
+    okw_d, okw_g, hkw_d, hkw_g = {}, {}, {}, {}
+    if cfg.n_labels:                                   # class-conditional variant
+        okw_d = dict(labels=batch["labels"], cls_z=batch["cls_z_d"])
+        okw_g = dict(cls_z=batch["cls_z_g"])
+        hkw_d = dict(labels=cu(batch["labels"]), cls_z=cu(batch["cls_z_d"]))
+        hkw_g = dict(cls_z=cu(batch["cls_z_g"]))
 
     # ---------------- gradient parity, D op ----------------
-    ro = tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], apply=False)
-    ho = gan.d_step(real, z_d, a_r, a_fd, apply=False)
+    ro = tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], apply=False, **okw_d)
+    ho = gan.d_step(real, z_d, a_r, a_fd, apply=False, **hkw_d)
     assert _loss_close(ho["d_loss"].item(), ro["d_loss"].item()), (ho["d_loss"].item(), ro["d_loss"].item())
+    if cfg.n_labels:
+        assert _loss_close(ho["d_cls_loss"].item(), ro["d_cls_loss"].item())
     assert rel_err(t2n(ho["real_logits"]), ro["real_logits"].detach().numpy()) < GRAD_TOL
     assert rel_err(t2n(ho["fake_logits"]), ro["fake_logits"].detach().numpy()) < GRAD_TOL
     assert rel_err(t2n(ho["fake"]), ro["fake"].detach().numpy()) < GRAD_TOL
     def rerun_d():
         gan.store.load_arrays(hip0, reset_ema=False)
-        gan.d_step(real, z_d, a_r, a_fd, apply=False)
+        gan.d_step(real, z_d, a_r, a_fd, apply=False, **hkw_d)
     _check_grads("d grad", gan, ro["grads"], rerun_d)
     tr.vs.state_updates.clear()
     gan.store.load_arrays(hip0, reset_ema=False)                  # undo the in-place u / BN-stat updates
 
     # ---------------- gradient parity, G op ----------------
-    ro = tr.g_step(batch["z_g"], batch["aug_fake_g"], apply=False)
-    ho = gan.g_step(B, z_g, a_fg, apply=False)
-    assert _loss_close(ho["g_adv"].item(), ro["g_adv"].item()), (ho["g_adv"].item(), ro["g_adv"].item())
+    ro = tr.g_step(batch["z_g"], batch["aug_fake_g"], apply=False, **okw_g)
+    ho = gan.g_step(B, z_g, a_fg, apply=False, **hkw_g)
+    if cfg.n_labels:
+        assert _loss_close(ho["g_cls_loss"].item(), ro["g_cls_loss"].item())
+    ro_adv = ro["g_adv"].item() + (ro["g_cls_loss"].item() if cfg.n_labels else 0.0)   # product folds the label loss in
+    assert _loss_close(ho["g_adv"].item(), ro_adv), (ho["g_adv"].item(), ro_adv)
     assert _loss_close(ho["g_loss"].item(), ro["g_loss"].item()), (ho["g_loss"].item(), ro["g_loss"].item())
     if cfg.g_regularization != "none":
         assert _loss_close(ho["g_reg"].item(), ro["g_reg"].item())
     assert rel_err(t2n(ho["fake_logits"]), ro["fake_logits"].detach().numpy()) < GRAD_TOL
     def rerun_g():
         gan.store.load_arrays(hip0, reset_ema=False)
-        gan.g_step(B, z_g, a_fg, apply=False)
+        gan.g_step(B, z_g, a_fg, apply=False, **hkw_g)
     _check_grads("g grad", gan, ro["grads"], rerun_g)
     tr.vs.state_updates.clear()
     gan.store.load_arrays(hip0, reset_ema=False)
@@ -123,8 +134,8 @@ def _run_parity(tr, gan, batch, check_state=True):
         return
 
     # ---------------- one full iteration: D update then G update ----------------
-    tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"])
-    gan.d_step(real, z_d, a_r, a_fd)
+    tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], **okw_d)
+    gan.d_step(real, z_d, a_r, a_fd, **hkw_d)
     after = tr.vs.export()
     hip1 = gan.store.export_arrays()
     for k in after:
@@ -138,8 +149,8 @@ def _run_parity(tr, gan, batch, check_state=True):
             assert not np.array_equal(hip1[k], hip0[k]), ("must change in the D step", k)
             e = rel_err(hip1[k], after[k])
             assert e < STATE_TOL, ("d-step state", k, e)
-    ro = tr.g_step(batch["z_g"], batch["aug_fake_g"])
-    ho = gan.g_step(B, z_g, a_fg)
+    ro = tr.g_step(batch["z_g"], batch["aug_fake_g"], **okw_g)
+    ho = gan.g_step(B, z_g, a_fg, **hkw_g)
     assert abs(ho["g_loss"].item() - ro["g_loss"].item()) <= 1e-3 * max(abs(ro["g_loss"].item()), 1e-6)
     after2 = tr.vs.export()
     hip2 = gan.store.export_arrays()
@@ -204,6 +215,58 @@ def test_plumbing_config_img64_ch32_batch16():
     # run to run (fp64 accumulators in every forward reduction), so the choice of seed is stable.
     batch = RM.synthetic_batch(tr.cfg, 29, 16)
     _run_parity(tr, gan, batch, check_state=False)
+
+
+def test_step_parity_class_conditional():
+    """--n_labels 10: labels concatenated to every z chunk, DC_logit head without SN,
+    5 x sigmoid-CE on the real half in d_loss, 1 x on the fakes in g_loss (BigGAN.py:346-365,689-701,853,894)."""
+    tr = oracle_trainer(64, 8, 64, 4, n_labels=10)
+    gan = hip_model_like(tr, n_labels=10)
+    assert "discriminator/DC_logit/kernel" in gan.store.vars and "discriminator/DC_logit/u" not in gan.store.vars
+    assert tuple(gan.store.vars["generator/first/dense1/kernel"].shape) == \
+        tuple(tr.vs.vars["generator/first/dense1/kernel"].shape)
+    batch = RM.synthetic_batch(tr.cfg, 11, 4)
+    _run_parity(tr, gan, batch)
+
+
+def test_virtual_batches_accumulate_and_average():
+    """--virtual_batches 2 (utils.py:242-320): gradients of two passes are summed, applied once scaled 1/2;
+    state updates (u, BN statistics) advance on every pass; the reported loss is the mean."""
+    tr = oracle_trainer(64, 8, 64, 2)
+    gan = hip_model_like(tr, virtual_batches=2)
+    b0, b1 = RM.synthetic_batch(tr.cfg, 31, 2), RM.synthetic_batch(tr.cfg, 32, 2)
+    hip0 = gan.store.export_arrays()
+    r0 = tr.d_step(b0["real"], b0["z_d"], b0["aug_real"], b0["aug_fake_d"], apply=False)
+    tr.vs.commit()
+    r1 = tr.d_step(b1["real"], b1["z_d"], b1["aug_real"], b1["aug_fake_d"], apply=False)
+    ho = gan.d_step([cu(b0["real"]), cu(b1["real"])], [cu(b0["z_d"]), cu(b1["z_d"])],
+                    [dev_draws(b0["aug_real"]), dev_draws(b1["aug_real"])],
+                    [dev_draws(b0["aug_fake_d"]), dev_draws(b1["aug_fake_d"])], apply=False)
+    mean_loss = 0.5 * (r0["d_loss"].item() + r1["d_loss"].item())
+    assert _loss_close(ho["d_loss"].item(), mean_loss), (ho["d_loss"].item(), mean_loss)
+    summed = {k: r0["grads"][k] + r1["grads"][k] for k in r0["grads"]}
+    _check_grads("virtual-batch d grad", gan, summed)
+    # the update uses the averaged gradient: Adam(beta1=0) step = -lr_t * g / (sqrt(v) + eps) is scale
+    # invariant up to eps, so compare against an oracle Adam step on summed/2
+    gan.store.load_arrays(hip0, reset_ema=False)
+    tr2 = oracle_trainer(64, 8, 64, 2)
+    r0 = tr2.d_step(b0["real"], b0["z_d"], b0["aug_real"], b0["aug_fake_d"], apply=False)
+    tr2.vs.commit()
+    r1 = tr2.d_step(b1["real"], b1["z_d"], b1["aug_real"], b1["aug_fake_d"], apply=False)
+    params = tr2.d_params()
+    tr2.d_opt.step(params, {k: 0.5 * (r0["grads"][k] + r1["grads"][k]) for k in params})
+    tr2.vs.commit()
+    gan.d_step([cu(b0["real"]), cu(b1["real"])], [cu(b0["z_d"]), cu(b1["z_d"])],
+               [dev_draws(b0["aug_real"]), dev_draws(b1["aug_real"])],
+               [dev_draws(b0["aug_fake_d"]), dev_draws(b1["aug_fake_d"])])
+    after = tr2.vs.export()
+    hip1 = gan.store.export_arrays()
+    for k in after:
+        if _noise_driven(k) or (k.endswith("/u") and after[k].size == 1):
+            continue
+        if "discriminator" in k or k.endswith("/u") or "pop_" in k or "moving_" in k:
+            e = rel_err(hip1[k], after[k])
+            assert e < STATE_TOL, ("virtual-batch state", k, e)
 
 
 def test_extension_32px():

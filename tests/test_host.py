@@ -48,9 +48,24 @@ def test_check_args_creates_folders(tmp_path):
     assert all(os.path.isdir(x) for x in d)
 
 
+def test_class_conditional_manifest_on_cpu():
+    """--n_labels widens first/dense1 and every cond-BN FC by n_labels and adds DC_logit without SN
+    (BigGAN.py:346-365, 433, 689-701); built on the meta device, no GPU needed."""
+    g = model.BigGAN(M.parse_args(["--gan_type", "hinge", "--img_size", "128", "--ch", "8", "--n_labels", "10",
+                                   "--virtual_batches", "2"], make_dirs=False),
+                     device="cpu", store=S.VariableStore("cpu"))
+    g.build_model()
+    v = g.store.vars
+    assert tuple(v["generator/first/dense1/kernel"].shape) == (106, 200)          # (96+10), round_up(106*1.85, 8)
+    assert tuple(v["generator/resblock_up_16/res1/batch_norm/beta/kernel"].shape)[0] == 42
+    assert tuple(v["discriminator/DC_logit/kernel"].shape) == (128, 10)
+    assert "discriminator/DC_logit/u" not in v and "discriminator/D_logit/u" in v
+    assert g.virtual_batches == 2
+
+
 def test_out_of_scope_flags_rejected_at_build():
-    for extra in (["--deep", "true"], ["--n_labels", "10"], ["--gan_type", "ra-dragan"], ["--g_final_layer", "true"],
-                  ["--bn_type", "batch_renorm"], ["--virtual_batches", "2"]):
+    for extra in (["--deep", "true"], ["--cls_embedding", "true"], ["--gan_type", "ra-dragan"], ["--g_final_layer", "true"],
+                  ["--bn_type", "batch_renorm"], ["--d_cls_dense_layers", "true"]):
         argv = ["--gan_type", "hinge", "--img_size", "64"] + extra
         with pytest.raises(NotImplementedError):
             model.BigGAN(M.parse_args(argv, make_dirs=False), device="cpu", store=S.VariableStore("cpu"))
