@@ -233,7 +233,10 @@ class DenseFn(Function):
 
 class AttentionFn(Function):
     """softmax(g f^T) h  (ops.py:481-485): q [B,N,dq], k [B,Nk,dq], v [B,Nk,dv] -> o [B,N,dv].
-    The [B,N,Nk] probabilities are materialised once (fp32) and kept for backward."""
+    Fused (flash-style) kernels when the shape is supported (bg_attention2_supported): the [B,N,Nk]
+    probabilities are never materialised; otherwise two GEMMs + softmax with P kept for backward."""
+
+    flash = True          # tests flip this to exercise the materialised form on supported shapes
 
     @staticmethod
     def forward(ctx, q, k, v):
@@ -241,10 +244,16 @@ class AttentionFn(Function):
         B, N, dq = q.shape
         Nk, dv = k.shape[1], v.shape[2]
         L = lib()
+        o = torch.empty((B, N, dv), dtype=torch.float32, device=q.device)
+        ctx.fused = bool(AttentionFn.flash and L.bg_attention2_supported(N, Nk, dq, dv))
+        if ctx.fused:
+            lse = torch.empty((B, N), dtype=torch.float32, device=q.device)
+            check(L.bg_attention2_fwd(f32(q), f32(k), f32(v), f32(o), f32(lse), B, N, Nk, dq, dv, stream()))
+            ctx.save_for_backward(q, k, v, o, lse)
+            return o
         p = torch.empty((B, N, Nk), dtype=torch.float32, device=q.device)
         gemm(q, k, p, N, Nk, dq, dq, dq, Nk, transB=True, batch=B, sA=N * dq, sB=Nk * dq, sC=N * Nk)
         check(L.bg_softmax_fwd(f32(p), f32(p), B * N, Nk, stream()))
-        o = torch.empty((B, N, dv), dtype=torch.float32, device=q.device)
         gemm(p, v, o, N, dv, Nk, Nk, dv, dv, batch=B, sA=N * Nk, sB=Nk * dv, sC=N * dv)
         ctx.save_for_backward(q, k, v, p)
         return o
@@ -252,10 +261,19 @@ class AttentionFn(Function):
     @staticmethod
     def backward(ctx, do):
         do = _c(do)
+        L = lib()
+        if ctx.fused:
+            q, k, v, o, lse = ctx.saved_tensors
+            B, N, dq = q.shape
+            Nk, dv = k.shape[1], v.shape[2]
+            dqq, dkk, dvv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            delta = torch.empty((B, N), dtype=torch.float32, device=q.device)
+            check(L.bg_attention2_bwd(f32(q), f32(k), f32(v), f32(o), f32(do), f32(lse), f32(dqq), f32(dkk), f32(dvv),
+                                      f32(delta), B, N, Nk, dq, dv, stream()))
+            return dqq, dkk, dvv
         q, k, v, p = ctx.saved_tensors
         B, N, dq = q.shape
         Nk, dv = k.shape[1], v.shape[2]
-        L = lib()
         dev = q.device
         # dV = P^T dO
         dvv = torch.empty_like(v)

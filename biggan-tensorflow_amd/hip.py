@@ -63,6 +63,9 @@ SIGNATURES = {
     "bg_rgbconv_wgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
     "bg_gemm_workspace_bytes": (c_size_t, [_GD]),
     "bg_gemm": (c_int, [_GD, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "bg_attention2_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "bg_attention2_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bg_attention2_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bg_spectral_norm_workspace_bytes": (c_size_t, [c_int, c_int]),
     "bg_spectral_norm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
     "bg_spectral_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),

@@ -116,6 +116,21 @@ int bg_gemm(const BgGemmDesc*, const float* A, const float* B, const float* bias
             const float* alpha_dev, float* C, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Fused attention of self_attention_2 (ops.py:481-485): o = softmax(q k^T) v, no 1/sqrt(d) scale.
+ *   q [B,N,d], k [B,Nk,d], v [B,Nk,dv], o [B,N,dv], lse [B,N] (= max + log sum exp of each query's
+ *   logits, kept for backward).  The [N,Nk] logits/probabilities are never written to memory; backward
+ *   recomputes them (delta_ws: B*N floats of scratch).  fp32 MFMA, deterministic (no atomics).
+ *   Supported when N % 128 == 0, Nk % 128 == 0, d % 4 == 0, dv % 4 == 0, d <= 32, dv <= 128
+ *   (bg_attention2_supported); other shapes use bg_gemm + bg_softmax_* (materialised form).
+ * ------------------------------------------------------------------------------------------ */
+int bg_attention2_supported(int N, int Nk, int d, int dv);
+int bg_attention2_fwd(const float* q, const float* k, const float* v, float* o, float* lse,
+                      int B, int N, int Nk, int d, int dv, void* stream);
+int bg_attention2_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                      const float* lse, float* dq, float* dk, float* dv_out, float* delta_ws,
+                      int B, int N, int Nk, int d, int dv, void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * Spectral norm, one power iteration (ops.py:718-747).  W is [rows, cols] (= reshape(w,[-1,last])).
  *   v = l2n(u W^T), u_out = l2n(v W), sigma = |v W|, w_norm = W / sigma.
  *   l2n(t) = t * rsqrt(max(sum t^2, 1e-12)).  scratch: bg_spectral_norm_workspace_bytes (fp64 accumulators).

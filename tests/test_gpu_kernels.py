@@ -221,9 +221,24 @@ def test_dense_on_column_slice_without_copy():
     assert rel_err(t2n(y), z[:, 96:128] @ w) < TOL
 
 
-@pytest.mark.parametrize("B,N,Nk,dq,dv", [(2, 256, 64, 2, 8), (3, 1024, 256, 8, 32), (1, 4096, 1024, 16, 64)])
-def test_attention_fwd_bwd(B, N, Nk, dq, dv):
+@pytest.mark.parametrize("B,N,Nk,dq,dv,fused", [
+    (2, 256, 64, 2, 8, False),            # unsupported by the fused kernels: materialised form
+    (3, 1024, 256, 8, 32, True), (3, 1024, 256, 8, 32, False),
+    (1, 4096, 1024, 16, 64, True), (1, 4096, 1024, 16, 64, False),
+    (2, 128, 128, 4, 16, True), (2, 512, 128, 12, 48, True), (1, 256, 256, 24, 96, True),
+    (2, 256, 128, 32, 128, True), (1, 384, 128, 20, 72, True)])
+def test_attention_fwd_bwd(B, N, Nk, dq, dv, fused):
     Fn = _fn()
+    from biggan_tensorflow_amd import hip
+    assert bool(hip.lib().bg_attention2_supported(N, Nk, dq, dv)) == (fused or (N, Nk) != (256, 64))
+    Fn.AttentionFn.flash = fused
+    try:
+        _attention_case(Fn, B, N, Nk, dq, dv)
+    finally:
+        Fn.AttentionFn.flash = True
+
+
+def _attention_case(Fn, B, N, Nk, dq, dv):
     rng = np.random.default_rng(N + dq)
     q, k, v = rng.standard_normal((B, N, dq)), rng.standard_normal((B, Nk, dq)), rng.standard_normal((B, Nk, dv))
     qt, kt, vt = (torch.tensor(a, requires_grad=True) for a in (q, k, v))
