@@ -32,8 +32,10 @@ WORKLOADS = {
     # bf16-compute conv / transposed-conv GEMMs (operands rounded to bf16 in LDS, fp32 accumulate, fp32 HBM tensors)
     "c3": (128, 96, 32, "BigGAN-128 ch=96 batch=32/GPU (256 over 8 GPUs) bf16 conv compute (BASELINE config 3)"),
     "c2bf16": (128, 64, 64, "BigGAN-128 ch=64 batch=64/GPU bf16 conv compute (config 2 shape)"),
+    "c4": (256, 96, 32, "BigGAN-256 ch=96 batch=32/GPU (256 over 8 GPUs) bf16 conv compute + DiffAugment (BASELINE config 4)"),
+    "c5": (512, 128, 64, "BigGAN-512 ch=128 batch=64/GPU (512 over 8 GPUs) bf16 conv compute (BASELINE config 5)"),
 }
-BF16_WORKLOADS = ("c3", "c2bf16")
+BF16_WORKLOADS = ("c3", "c2bf16", "c4", "c5")
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2516.6     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)

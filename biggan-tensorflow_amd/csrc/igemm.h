@@ -44,6 +44,8 @@ struct NNParams {
     int64_t slab_stride;    // elements per slab
     int64_t strideA, strideB, strideC;
     int32_t tiles_m, tiles_n;
+    int32_t kchunk;         // K-steps per channel chunk of the (chunk, tap, step) K order; 0 = all channels
+    int32_t zfold;          // >0: gridDim.z folded into blockIdx.x, z fastest (phases of one M-tile share an L2)
 };
 
 struct TNParams {
@@ -61,6 +63,7 @@ struct TNParams {
     int32_t batch;
     int64_t strideA, strideB, strideC;
     int32_t tiles_m, tiles_n;
+    int32_t zfold;          // >0: gridDim.z (batch * splitk) folded into blockIdx.x, split-major per XCD
     const float* alpha;
 };
 

@@ -11,6 +11,7 @@
 // A tiles are stored K-major in LDS ([k][m], row stride == 2 mod 8) so that both the transposing
 // ds_write_b32 (4 per float4) and the operand ds_read_b32 (lane = row) are bank-conflict free.
 // Blocks are renumbered so that the tiles sharing operand panels run on one XCD (shared L2).
+#include <stdlib.h>
 #include "common.h"
 #include "igemm.h"
 #include "igemm_dev.h"
@@ -72,11 +73,18 @@ __global__ __launch_bounds__(256, (TM * TN == 4 && !MIRROR) ? 4 : 1) void nn_ker
     const int wm = wave / WN, wn = wave % WN;
 
     const Gather& g = p.g;
-    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    int tile, bz = blockIdx.z;
+    if (p.zfold > 0) {
+        const int lin = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.zfold);
+        bz = lin % p.zfold;
+        tile = lin / p.zfold;
+    } else {
+        tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    }
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int zs = blockIdx.z % p.splitk, zo = blockIdx.z / p.splitk;
+    const int zs = bz % p.splitk, zo = bz / p.splitk;
     const float* Abase = p.A;
     const float* Bbase = p.B;
     float* Obase = p.out;
@@ -119,9 +127,22 @@ __global__ __launch_bounds__(256, (TM * TN == 4 && !MIRROR) ? 4 : 1) void nn_ker
     int64_t aoff[AROWS][NSRC];
 
     // load-stream state, positioned at iteration it0
-    int l_ic = it0 % kc;
-    int l_iw = (it0 / kc) % nkw;
-    int l_ih = (it0 / kc) / nkw;
+    // K order: channel chunks outermost, taps inside a chunk, K-steps of the chunk innermost.  The taps of
+    // one output tile gather overlapping input pixels, so walking all taps over a narrow channel chunk
+    // keeps the re-reads inside the XCD's 4 MB L2 instead of streaming the whole input once per tap.
+    const int kci = p.kchunk > 0 ? min(kc, p.kchunk) : kc;      // K-steps per chunk
+    const int nchunk = (kc + kci - 1) / kci;
+    const int ntap = nkh * nkw;
+    int l_chunk = min(it0 / (ntap * kci), nchunk - 1);
+    int l_csteps = min(kci, kc - l_chunk * kci);                // K-steps in the current chunk
+    int l_ic, l_iw, l_ih;
+    {
+        const int rem = it0 - l_chunk * ntap * kci;
+        const int tap = rem / l_csteps;
+        l_ic = rem - tap * l_csteps;
+        l_iw = tap % nkw;
+        l_ih = tap / nkw;
+    }
     bool need_off = true;
     float4 ra[AROWS];
     constexpr int BLOADS = BT ? (BN + 63) / 64 : (BKT * BN / 4 + 255) / 256;
@@ -134,7 +155,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4 && !MIRROR) ? 4 : 1) void nn_ker
             for (int i = 0; i < AROWS; ++i) tap_sources<MODE, MIRROR>(g, rows[i], kh, kw, aoff[i]);
             need_off = false;
         }
-        const int c0 = l_ic * BKT;
+        const int c0 = (l_chunk * kci + l_ic) * BKT;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
             float4 v = load_chan4<VEC>(Abase, aoff[i][0], c0 + a_kq, p.C);
@@ -189,11 +210,15 @@ __global__ __launch_bounds__(256, (TM * TN == 4 && !MIRROR) ? 4 : 1) void nn_ker
             }
         }
         // advance the load stream
-        if (++l_ic == kc) {
+        if (++l_ic == l_csteps) {
             l_ic = 0;
             if (++l_iw == nkw) {
                 l_iw = 0;
-                ++l_ih;
+                if (++l_ih == nkh) {
+                    l_ih = 0;
+                    ++l_chunk;
+                    l_csteps = min(kci, kc - l_chunk * kci);
+                }
             }
         }
     };
@@ -325,10 +350,20 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 4 : 1) void tn_kernel(const T
     const int wm = wave / WN, wn = wave % WN;
     const Gather& g = p.g;
 
-    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    int tile, bz = blockIdx.z;
+    if (p.zfold > 0) {
+        // split-major logical ids: every XCD owns whole pixel ranges (splits), so the slice of x / dy a
+        // split reduces over is fetched into ONE L2 and shared by all its (M, N) tiles
+        const int ntile = p.tiles_m * p.tiles_n;
+        const int lin = xcd_remap(blockIdx.x, ntile * p.zfold);
+        bz = lin / ntile;
+        tile = lin - bz * ntile;
+    } else {
+        tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    }
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
     const int mf0 = tile_m * BM, cb0 = tile_n * BN;
-    const int zb = blockIdx.z / p.splitk, zs = blockIdx.z % p.splitk;
+    const int zb = bz / p.splitk, zs = bz % p.splitk;
 
     const float* Abase = p.A + (int64_t)zb * p.strideA;
     const float* Bbase = p.Bv + (int64_t)zb * p.strideB;
@@ -556,6 +591,21 @@ static void launch_nn_tile(NNParams& p, const NNPlan& pl, bool vec, bool bf16, i
     p.tiles_m = (p.M + pl.bm - 1) / pl.bm;
     p.tiles_n = (p.N + pl.bn - 1) / pl.bn;
     dim3 grid(p.tiles_m * p.tiles_n, 1, zdim * p.splitk);
+    // stride-phase launches: the phases of one M-tile gather the same input rows, so run them back to back
+    // on one XCD (z fastest) instead of one phase after the other over the whole image
+    static const int zfold_mode = getenv("BG_ZFOLD") ? atoi(getenv("BG_ZFOLD")) : 1;
+    // (measured, round 1: a chunked K order costs more in per-tap index math than it saves in L2 misses:
+    //  off by default, kept as a tuning knob)
+    static const int kchunk_ch = getenv("BG_KCHUNK") ? atoi(getenv("BG_KCHUNK")) : 0;    // channels per chunk
+    const bool use_bf16 = bf16 && vec && pl.bn >= 64;
+    p.kchunk = (MODE == GATHER_PLAIN || kchunk_ch <= 0) ? 0 : (kchunk_ch + (use_bf16 ? 31 : 15)) / (use_bf16 ? 32 : 16);
+    p.zfold = 0;
+    // only when every phase has the same number of taps (k % stride == 0, e.g. k4 s2): unequal phases keep the
+    // heavy-phase-first z-major order, which balances the tail of the grid better
+    if (zfold_mode && MODE == GATHER_TCONV && zdim > 1 && p.splitk == 1 && p.g.k % p.g.stride == 0) {
+        p.zfold = zdim;
+        grid = dim3(p.tiles_m * p.tiles_n * zdim, 1, 1);
+    }
     if (bf16 && vec && pl.bn >= 64) {
         if (pl.bm == 128 && pl.bn == 128)
             hipLaunchKernelGGL((nn_kernel_bf16<2, 2, BT, MODE, MIRROR>), grid, dim3(256), 0, s, p);
@@ -683,6 +733,13 @@ static int launch_tn(TNParams& p, int mode, bool vec, float* final_out, void* ws
     p.tiles_m = (p.Mf + pl.bm - 1) / pl.bm;
     p.tiles_n = (p.Cb + pl.bn - 1) / pl.bn;
     dim3 grid(p.tiles_m * p.tiles_n, 1, p.batch * p.splitk);
+    // (measured, round 1: +20 % on two bf16 wgrad shapes, -5..-9 % on most fp32 ones: off by default)
+    static const int tn_zfold = getenv("BG_TN_ZFOLD") ? atoi(getenv("BG_TN_ZFOLD")) : 0;
+    p.zfold = 0;
+    if (tn_zfold && p.batch == 1 && p.splitk > 1) {
+        p.zfold = p.splitk;
+        grid = dim3(p.tiles_m * p.tiles_n * p.splitk, 1, 1);
+    }
     if (bf16 && pl.bn >= 64) {
         if (pl.bm == 128 && pl.bn == 128)
             hipLaunchKernelGGL((tn_kernel_bf16<2, 2, GATHER_CONV>), grid, dim3(256), 0, s, p);

@@ -72,11 +72,18 @@ __global__ __launch_bounds__(256) void nn_kernel_bf16(const NNParams p) {
     const int wm = wave / WN, wn = wave % WN;
 
     const Gather& g = p.g;
-    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    int tile, bz = blockIdx.z;
+    if (p.zfold > 0) {
+        const int lin = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.zfold);
+        bz = lin % p.zfold;
+        tile = lin / p.zfold;
+    } else {
+        tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    }
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int zs = blockIdx.z % p.splitk, zo = blockIdx.z / p.splitk;
+    const int zs = bz % p.splitk, zo = bz / p.splitk;
     const float* Abase = p.A;
     const float* Bbase = p.B;
     float* Obase = p.out;
@@ -114,9 +121,22 @@ __global__ __launch_bounds__(256) void nn_kernel_bf16(const NNParams p) {
     for (int i = 0; i < AITEMS; ++i) rows[i] = decompose_row<MODE>(g, m0 + (t >> 2) + 64 * i, p.M, ph, pw);
     int64_t aoff[AITEMS][NSRC];
 
-    int l_ic = it0 % kc;
-    int l_iw = (it0 / kc) % nkw;
-    int l_ih = (it0 / kc) / nkw;
+    // K order: channel chunks outermost, taps inside a chunk, K-steps of the chunk innermost.  The taps of
+    // one output tile gather overlapping input pixels, so walking all taps over a narrow channel chunk
+    // keeps the re-reads inside the XCD's 4 MB L2 instead of streaming the whole input once per tap.
+    const int kci = p.kchunk > 0 ? min(kc, p.kchunk) : kc;      // K-steps per chunk
+    const int nchunk = (kc + kci - 1) / kci;
+    const int ntap = nkh * nkw;
+    int l_chunk = min(it0 / (ntap * kci), nchunk - 1);
+    int l_csteps = min(kci, kc - l_chunk * kci);                // K-steps in the current chunk
+    int l_ic, l_iw, l_ih;
+    {
+        const int rem = it0 - l_chunk * ntap * kci;
+        const int tap = rem / l_csteps;
+        l_ic = rem - tap * l_csteps;
+        l_iw = tap % nkw;
+        l_ih = tap / nkw;
+    }
     bool need_off = true;
     float4 ra[AITEMS][2];
     constexpr int BREG = BT ? BITEMS_T * 2 : BITEMS_N * 4;
@@ -129,7 +149,7 @@ __global__ __launch_bounds__(256) void nn_kernel_bf16(const NNParams p) {
             for (int i = 0; i < AITEMS; ++i) tap_sources<MODE, MIRROR>(g, rows[i], kh, kw, aoff[i]);
             need_off = false;
         }
-        const int c0 = l_ic * BKB;
+        const int c0 = (l_chunk * kci + l_ic) * BKB;
 #pragma unroll
         for (int i = 0; i < AITEMS; ++i) {
 #pragma unroll
@@ -171,11 +191,15 @@ __global__ __launch_bounds__(256) void nn_kernel_bf16(const NNParams p) {
                 }
             }
         }
-        if (++l_ic == kc) {
+        if (++l_ic == l_csteps) {
             l_ic = 0;
             if (++l_iw == nkw) {
                 l_iw = 0;
-                ++l_ih;
+                if (++l_ih == nkh) {
+                    l_ih = 0;
+                    ++l_chunk;
+                    l_csteps = min(kci, kc - l_chunk * kci);
+                }
             }
         }
     };
@@ -288,10 +312,20 @@ __global__ __launch_bounds__(256) void tn_kernel_bf16(const TNParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const Gather& g = p.g;
 
-    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    int tile, bz = blockIdx.z;
+    if (p.zfold > 0) {
+        // split-major logical ids: every XCD owns whole pixel ranges (splits), so the slice of x / dy a
+        // split reduces over is fetched into ONE L2 and shared by all its (M, N) tiles
+        const int ntile = p.tiles_m * p.tiles_n;
+        const int lin = xcd_remap(blockIdx.x, ntile * p.zfold);
+        bz = lin / ntile;
+        tile = lin - bz * ntile;
+    } else {
+        tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    }
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
     const int mf0 = tile_m * BM, cb0 = tile_n * BN;
-    const int zb = blockIdx.z / p.splitk, zs = blockIdx.z % p.splitk;
+    const int zb = bz / p.splitk, zs = bz % p.splitk;
     const float* Abase = p.A + (int64_t)zb * p.strideA;
     const float* Bbase = p.Bv + (int64_t)zb * p.strideB;
 
