@@ -145,7 +145,7 @@ def pmc_traffic(workload):
         d = json.load(fh)
     n = b = 0.0
     for k, e in d.items():
-        if re.search(r"\b(nn|tn)_kernel", k) and "hbm_read_bytes_per_launch" in e:
+        if re.search(r"\b((nn|tn)_kernel|attn_(fwd|bwd))", k) and "hbm_read_bytes_per_launch" in e:
             n += e["launches"]
             b += e["launches"] * (e["hbm_read_bytes_per_launch"] + e.get("hbm_write_bytes_per_launch", 0.0))
     return (b / n if n else None), os.path.relpath(files[-1], ROOT)
@@ -239,7 +239,7 @@ def main():
                 "traffic_source": traffic_src,
                 "kernel": ("bg::nn_kernel_bf16 / bg::tn_kernel_bf16 (bf16 MFMA implicit GEMM: conv, deconv) + "
                            "fp32 bg::nn_kernel for dense / attention / 1x1 launches that stay fp32") if bf16 else
-                          "bg::nn_kernel / bg::tn_kernel (fp32 MFMA implicit GEMM: conv, deconv, dense, attention)",
+                          "bg::nn_kernel / bg::tn_kernel (fp32 MFMA implicit GEMM: conv, deconv, dense) + bg::attn_* (fused attention)",
                 "launches_per_step": int(n.value // nprof), "gemm_ms_per_step": round(ms.value / nprof, 3),
                 "gemm_flops_per_step": fl.value / nprof,
                 "step_algorithmic_flops": fpi * B,
@@ -247,7 +247,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        sb = 2 if img >= 128 else 8
+        sb = 4 if img >= 128 else 16
         note("cpu baseline (oracle, batch %d) ..." % sb)
         cpu = cpu_baseline(img, ch, sb, 1, note)
         note("cpu baseline done")

@@ -9,6 +9,7 @@ heads, class conditioning, non-hinge losses, gradient penalty, renorm) are accep
 rejected here with NotImplementedError.
 """
 import copy
+import os
 import math
 import time
 
@@ -579,6 +580,100 @@ class BigGAN(GANBase):
             for name, val in vals.items():
                 print_str += ", " + name + ": %.4f" % val
             print(print_str, flush=True)
+
+    # ---- sampling with the EMA weights (BigGAN.py:963-971) ------------------------------------
+    def sample(self, z=None, cls_z=None, B=None, use_ema=True):
+        """``self.fake_images``: generator(test_z, zero_cls_z, is_training=False, custom_getter=ema_getter).
+        Trainables are read from their ExponentialMovingAverage shadows, non-trainables (``u``, moving
+        statistics) from the live variables; batch norm uses the population statistics; the spectral-norm
+        power iteration still advances ``u`` (its assign is a control dependency of w / sigma, ops.py:743)."""
+        B = B or (z.shape[0] if z is not None else self.batch_size)
+        if z is None:
+            z = self.sample_z(B)
+        if self.acgan and cls_z is None:
+            cls_z = torch.zeros(B, self.n_labels, dtype=torch.float32, device=self.device)   # zero_cls_z
+        arena = self.g_arena
+        live = None
+        if use_ema and arena.ema is not None:
+            live = arena.params.clone()
+            arena.params.copy_(arena.ema)
+        try:
+            ops.begin_run(None, 1)
+            with torch.no_grad():
+                img = self.generator(z, cls_z, is_training=False, reuse=True)
+        finally:
+            if live is not None:
+                arena.params.copy_(live)
+        return img
+
+    # ---- checkpoints (BigGAN.py:1255-1284) ---------------------------------------------------
+    def _ckpt_dir(self, checkpoint_dir):
+        return os.path.join(checkpoint_dir, self.model_dir)
+
+    def state_tensors(self):
+        """name -> tensor, keyed like a TF checkpoint of the reference graph: variables by their scope
+        names, ``<var>/ExponentialMovingAverage`` shadows, Adam slots ``<var>/Adam`` (m) and ``<var>/Adam_1`` (v)."""
+        out = {}
+        for k, v in self.store.vars.items():
+            out[k] = v.detach()
+        for group, arena in self.store.arenas.items():
+            for name in arena.names:
+                out[name + "/Adam"] = arena.view(arena.m, name)
+                out[name + "/Adam_1"] = arena.view(arena.v, name)
+                if arena.ema is not None:
+                    out[name + "/ExponentialMovingAverage"] = arena.view(arena.ema, name)
+        return out
+
+    def save(self, checkpoint_dir, step):
+        """``<checkpoint_dir>/<model_dir>/BigGAN.model-<step>.safetensors`` + a TF-style ``checkpoint`` index."""
+        from safetensors.torch import save_file
+        d = self._ckpt_dir(checkpoint_dir)
+        os.makedirs(d, exist_ok=True)
+        tensors = {k: v.detach().to("cpu").contiguous().clone() for k, v in self.state_tensors().items()}
+        tensors["_meta/steps"] = torch.tensor([self.counter, self.d_arena.step, self.g_arena.step], dtype=torch.int64)
+        name = "%s.model-%d" % (self.model_name, int(step))
+        save_file(tensors, os.path.join(d, name + ".safetensors"))
+        with open(os.path.join(d, "checkpoint"), "w") as f:
+            f.write('model_checkpoint_path: "%s"\n' % name)
+        return os.path.join(d, name + ".safetensors")
+
+    def load_checkpoint(self, checkpoint_path):
+        from safetensors.torch import load_file
+        if not checkpoint_path.endswith(".safetensors"):
+            checkpoint_path += ".safetensors"
+        tensors = load_file(checkpoint_path)
+        dst = self.state_tensors()
+        missing = [k for k in dst if k not in tensors]
+        if missing:
+            raise KeyError("checkpoint %s lacks %d tensors, e.g. %s" % (checkpoint_path, len(missing), missing[:3]))
+        with torch.no_grad():
+            for k, t in dst.items():
+                src = tensors[k]
+                if tuple(src.shape) != tuple(t.shape):
+                    raise ValueError("checkpoint tensor %s has shape %s, model expects %s"
+                                     % (k, tuple(src.shape), tuple(t.shape)))
+                t.copy_(src.to(t.device))
+        steps = tensors.get("_meta/steps")
+        ckpt_name = os.path.basename(checkpoint_path)[:-len(".safetensors")]
+        counter = int(ckpt_name.split('-')[-1])
+        if steps is not None:
+            self.d_arena.step, self.g_arena.step = int(steps[1]), int(steps[2])
+        self.counter = counter
+        print(" [*] Successfully read {}".format(ckpt_name))
+        return True, counter
+
+    def load(self, checkpoint_dir):
+        print(" [*] Reading checkpoints...")
+        d = self._ckpt_dir(checkpoint_dir)
+        if getattr(self.args, "checkpoint", ""):
+            return self.load_checkpoint(self.args.checkpoint)
+        index = os.path.join(d, "checkpoint")
+        if os.path.exists(index):
+            line = open(index).read().strip().splitlines()[0]
+            name = line.split(":", 1)[1].strip().strip('"')
+            return self.load_checkpoint(os.path.join(d, name))
+        print(" [*] Failed to find a checkpoint")
+        return False, 0
 
     @property
     def model_dir(self):

@@ -288,6 +288,27 @@ class Trainer:
         return {"g_loss": g_loss, "g_adv": g_adv, "g_reg": reg, "fake_logits": d_fake["real"],
                 "fake": fake, "g_cls_loss": g_cls}
 
+    def sample(self, z, cls_z=None, commit=True):
+        """BigGAN.py:963-971: generator(test_z, zero_cls_z, is_training=False) reading the trainables through
+        ema_getter (ExponentialMovingAverage shadows); ``u`` still advances (ops.py:743)."""
+        cfg, vs = self.cfg, self.vs
+        vs.state_updates.clear()
+        live = {k: vs.vars[k] for k in self.ema}
+        for k, e in self.ema.items():
+            vs.vars[k] = e
+        try:
+            if cfg.n_labels and cls_z is None:
+                cls_z = np.zeros((np.asarray(z).shape[0], cfg.n_labels), np.float32)
+            cz = self._t(cls_z) if cfg.n_labels else None
+            with torch.no_grad():
+                img = generator(vs, cfg, self._t(z), cz, False)
+        finally:
+            for k, v in live.items():
+                vs.vars[k] = v
+        if commit:
+            vs.commit()
+        return img
+
     def d_step(self, real, z, aug_real, aug_fake, labels=None, cls_z=None, apply=True):
         out = self.d_forward(real, z, aug_real, aug_fake, labels, cls_z)
         params = self.d_params()

