@@ -67,7 +67,7 @@ class BigGAN(GANBase):
             ("z_reconstruct", args.z_reconstruct), ("d_reconstruction", args.d_reconstruction),
             ("d_reconstruction_halfres", args.d_reconstruction_halfres),
             ("d_reconstruction_texture", args.d_reconstruction_texture), ("d_final_conv", args.d_final_conv),
-            ("bn_in_d", args.bn_in_d), ("c_dim!=3", args.c_dim != 3),
+            ("c_dim!=3", args.c_dim != 3),
             ("not g_first_level_dense_layer", not args.g_first_level_dense_layer),
         ]
         bad = [n for n, v in unsupported if v]
@@ -85,7 +85,11 @@ class BigGAN(GANBase):
         elif self.activation == 'prelu':
             self.activation_fn = prelu
         elif self.activation == 'lrelu':
-            raise NotImplementedError("--activation lrelu is outside the default hot path")
+            def lrelu_p(alpha):
+                def lrelu_a(x):
+                    return lrelu(x, alpha)
+                return lrelu_a
+            self.activation_fn = lrelu_p(0.2)                                          # BigGAN.py:76-81
         else:
             raise ValueError("Unknown activation function: " + str(self.activation))
 
@@ -436,15 +440,22 @@ class BigGAN(GANBase):
             fake = self.generator(z, cls_z, is_training=True)
         real_aug = DiffAugment(real, policy=self.da_policy, draws=draws_real, generator=self.gen)
         fake_aug = DiffAugment(fake, policy=self.da_policy, draws=draws_fake, generator=self.gen)
-        d_out = self.discriminator(torch.cat([real_aug, fake_aug], dim=0))
-        logits = d_out["real"]
-        real_logits, fake_logits = logits[:B], logits[B:]
+        if self.bn_in_d:
+            # batch norm couples the samples of a call: keep the reference's two instantiations
+            # (BigGAN.py:807,857), each with its own batch statistics; moving statistics compound
+            d_real, d_fake = self.discriminator(real_aug), self.discriminator(fake_aug, reuse=True)
+            real_logits, fake_logits = d_real["real"], d_fake["real"]
+            d_out = d_real
+        else:
+            d_out = self.discriminator(torch.cat([real_aug, fake_aug], dim=0))
+            logits = d_out["real"]
+            real_logits, fake_logits = logits[:B], logits[B:]
         d_loss = discriminator_loss(self.d_loss_func, real=real_logits, fake=fake_logits, flood_level=self.d_flood)
         out = {"real_logits": real_logits, "fake_logits": fake_logits, "fake": fake}
         if self.acgan:
             if labels is None:
                 raise ValueError("n_labels > 0: d_forward needs the labels of the real batch")
-            real_cls = d_out["cls"][:B]
+            real_cls = d_out["cls"][:B]             # (a no-op slice when D ran on the real batch alone)
             d_cls = self._cls_loss()(labels, real_cls, self.d_cls_loss_weight, self._reduce_fn(), self.world)
             out["d_cls_loss"] = d_cls
             d_loss = Fn.AddFn.apply(d_loss, d_cls)

@@ -26,6 +26,7 @@ gan_dtype = torch.float32
 class _Run:
     def __init__(self):
         self.sn_cache = {}       # variable name -> w / sigma of this run (one power iteration per run)
+        self.sn_prefetched = set()
         self.reg_losses = []     # tf.losses.get_regularization_losses()
         self.reg_seen = set()
         self.reduce_fn = None    # in-place SUM all-reduce of a small fp32 tensor across DP ranks
@@ -38,6 +39,7 @@ _run = _Run()
 def begin_run(reduce_fn=None, world=1):
     """Start of one ``sess.run``: forget cached spectral norms and regularisation losses."""
     _run.sn_cache = {}
+    _run.sn_prefetched = set()
     _run.reg_losses = []
     _run.reg_seen = set()
     _run.reduce_fn = reduce_fn
@@ -47,8 +49,9 @@ def begin_run(reduce_fn=None, world=1):
 def sn_prefetch(batch):
     """Run the power iteration of every spectrally-normalised weight of a network in one multi-tensor
     call (functional.SnBatch) and put the results where ``spectral_norm`` looks first."""
-    if batch is None:
-        return
+    if batch is None or id(batch) in _run.sn_prefetched:
+        return                  # a second instantiation of the network in the same run reuses the first
+    _run.sn_prefetched.add(id(batch))
     needs_base = torch.is_grad_enabled()
     for w, wn in zip(batch.w, batch.forward()):
         _run.sn_cache[w.bg_name] = (wn, needs_base and w.requires_grad)

@@ -31,6 +31,8 @@ class Config:
         self.g_regularization = "ortho_cosine"
         self.g_regularization_factor = 1e-4
         self.conv_padding = "reflect"
+        self.activation = "prelu"             # main.py:63
+        self.bn_in_d = False                  # main.py:40
         self.g_grow_factor = 2.0
         self.d_grow_factor = 2.0
         self.gan_type = "hinge"
@@ -101,7 +103,8 @@ class Config:
 
 def _conv_opt(cfg, training, generator):
     opt = {"sn": cfg.sn, "padding_type": cfg.conv_padding, "bn_momentum": cfg.bn_momentum,
-           "self_attention_bias": cfg.bias_in_sa, "regularizer": None}
+           "self_attention_bias": cfg.bias_in_sa, "regularizer": None, "act": cfg.activation,
+           "bn_in_d": cfg.bn_in_d}
     if generator and training and cfg.g_regularization != "none":           # BigGAN.py:257-274
         opt["regularizer"] = {"scale": cfg.g_regularization_factor, "type": cfg.g_regularization}
     return opt
@@ -127,9 +130,10 @@ def generator(vs, cfg, z, cls_z=None, is_training=True):
 
     zi = next(nxt)
     f_width = R.round_up((sizes[zi] + cfg.n_labels) * 1.85, 8)               # BigGAN.py:433
-    x = R.fully_connected(vs, G + "/first/dense1", z_split[zi], f_width, opt)  # BigGAN.py:440-443
-    x = R.prelu(vs, G + "/first/prelu", x)
-    x = R.fully_connected(vs, G + "/first/dense2", x, 4 * 4 * ch, opt)
+    first = G if cfg.activation == "relu" else G + "/first"              # BigGAN.py:434-443: no scope with relu
+    x = R.fully_connected(vs, first + "/dense1", z_split[zi], f_width, opt)
+    x = R.activation(vs, first + "/prelu", x, opt)
+    x = R.fully_connected(vs, first + "/dense2", x, 4 * 4 * ch, opt)
     x = x.reshape(-1, 4, 4, ch)                                             # BigGAN.py:446
 
     b_i = 0
@@ -148,7 +152,7 @@ def generator(vs, cfg, z, cls_z=None, is_training=True):
         ch_mul //= 2
 
     x = R.batch_norm(vs, G + "/batch_norm", x, opt, is_training)            # BigGAN.py:491
-    x = R.prelu(vs, G + "/prelu", x)                                        # BigGAN.py:492
+    x = R.activation(vs, G + "/prelu", x, opt)                                        # BigGAN.py:492
     x = R.conv(vs, G + "/G_logit", x, cfg.c_dim, opt, kernel=3, stride=1, pad=1, use_bias=False)  # :570
     return torch.tanh(x)                                                    # :580
 
@@ -174,7 +178,7 @@ def discriminator(vs, cfg, x):
         ch_mul *= 2
     ch = cfg.scale_channels(cfg.d_ch, cfg.d_grow_factor ** (b_i - 1))       # BigGAN.py:666
     x = R.resblock(vs, D + "/resblock", x, ch, opt, use_bias=cfg.bias_in_d)  # :668
-    x = R.prelu(vs, D + "/prelu", x)                                        # :669
+    x = R.activation(vs, D + "/prelu", x, opt)                                        # :669
     feat = R.global_sum_pooling(x)                                          # :671
     out = {}
     out["real"] = R.fully_connected(vs, D + "/D_logit", feat, 1, opt,

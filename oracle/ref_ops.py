@@ -66,6 +66,11 @@ class VarStore:
         """tf.assign executed as a control dependency: recorded, applied by commit()."""
         self.state_updates[name] = value.detach().clone()
 
+    def current(self, name):
+        """Value a second update op of the same run starts from (tf.layers' moving averages are
+        assign_sub ops: two instantiations of the layer in one run compound)."""
+        return self.state_updates.get(name, self.vars[name].detach())
+
     def commit(self):
         for k, v in self.state_updates.items():
             with torch.no_grad():
@@ -271,6 +276,19 @@ def prelu(vs, scope, x):
     return torch.relu(x) + alpha * (x - x.abs()) * 0.5
 
 
+def activation(vs, scope, x, opt):
+    """opt['act'] (BigGAN.py:71-83): 'prelu' (ops.py:532, variable <scope>/alpha), 'relu' (529) or
+    'lrelu' = tf.nn.leaky_relu(x, 0.2) (525, BigGAN.py:79)."""
+    kind = opt.get("act", "prelu")
+    if kind == "prelu":
+        return prelu(vs, scope, x)
+    if kind == "relu":
+        return torch.relu(x)
+    if kind == "lrelu":
+        return F.leaky_relu(x, 0.2)
+    raise ValueError("Unknown activation function: " + str(kind))
+
+
 def max_pooling(x):                               # ops.py:508-510 (even H, W: 2x2 windows)
     return _nhwc(F.max_pool2d(_nchw(x), 2, 2))
 
@@ -320,8 +338,11 @@ def batch_norm(vs, scope, x, opt, is_training=True):
         mean = x.mean(dim=(0, 1, 2))
         var = ((x - mean) ** 2).mean(dim=(0, 1, 2))
         n = x.shape[0] * x.shape[1] * x.shape[2]
-        vs.assign(scope + "/moving_mean", mm * decay + mean * (1 - decay))
-        vs.assign(scope + "/moving_variance", mv * decay + var * (n / max(n - 1, 1)) * (1 - decay))
+        # with --bn_in_d the discriminator is instantiated twice per run (real, fake): the second update
+        # starts from the first one's result (assign_moving_average); order real -> fake as in d_forward
+        mm_c, mv_c = vs.current(scope + "/moving_mean"), vs.current(scope + "/moving_variance")
+        vs.assign(scope + "/moving_mean", mm_c * decay + mean * (1 - decay))
+        vs.assign(scope + "/moving_variance", mv_c * decay + var * (n / max(n - 1, 1)) * (1 - decay))
     else:
         mean, var = mm, mv
     inv = torch.rsqrt(var + BN_EPS) * gamma
@@ -332,30 +353,39 @@ def batch_norm(vs, scope, x, opt, is_training=True):
 # residual blocks / attention   (ops.py:187-313, 467-492)
 # ----------------------------------------------------------------------------------
 def resblock(vs, scope, x_init, channels, opt, use_bias=True):
-    """ops.py:187-198 (bn_in_d False)."""
+    """ops.py:187-198."""
     x = conv(vs, scope + "/res1/conv_0", x_init, channels, opt, kernel=3, stride=1, pad=1, use_bias=use_bias)
-    x = prelu(vs, scope + "/res1/prelu", x)
+    if opt.get("bn_in_d"):
+        x = batch_norm(vs, scope + "/res1/batch_norm", x, opt, True)
+    x = activation(vs, scope + "/res1/prelu", x, opt)
     x = conv(vs, scope + "/res2/conv_0", x, channels, opt, kernel=3, stride=1, pad=1, use_bias=use_bias)
+    if opt.get("bn_in_d"):
+        x = batch_norm(vs, scope + "/res2/batch_norm", x, opt, True)
     return x + x_init
 
 
 def resblock_up_condition(vs, scope, x_init, z, channels, opt, use_bias=True, is_training=True):
     """ops.py:250-266 with upconv = deconv k4 s2 (ops.py:203-204), g_conv = deconv k3 s1 (221-222)."""
     x = condition_batch_norm(vs, scope + "/res1/batch_norm", x_init, z, opt, is_training)
-    x = prelu(vs, scope + "/res1/prelu", x)
+    x = activation(vs, scope + "/res1/prelu", x, opt)
     x = deconv(vs, scope + "/res1/deconv_0", x, channels, opt, kernel=4, stride=2, use_bias=use_bias)
     x = condition_batch_norm(vs, scope + "/res2/batch_norm", x, z, opt, is_training)
-    x = prelu(vs, scope + "/res2/prelu", x)
+    x = activation(vs, scope + "/res2/prelu", x, opt)
     x = deconv(vs, scope + "/res2/deconv_0", x, channels, opt, kernel=3, stride=1, use_bias=use_bias)
     skip = deconv(vs, scope + "/skip/deconv_0", x_init, channels, opt, kernel=4, stride=2, use_bias=use_bias)
     return x + skip
 
 
 def resblock_down(vs, scope, x_init, channels, opt, use_bias=True):
-    """ops.py:293-313 with downconv = conv k3 s2 pad 1 (ops.py:273-274), bn_in_d False."""
-    x = prelu(vs, scope + "/res1/prelu", x_init)
+    """ops.py:293-313 with downconv = conv k3 s2 pad 1 (ops.py:273-274)."""
+    x = x_init
+    if opt.get("bn_in_d"):
+        x = batch_norm(vs, scope + "/res1/batch_norm", x, opt, True)
+    x = activation(vs, scope + "/res1/prelu", x, opt)
     x = conv(vs, scope + "/res1/conv_0", x, channels, opt, kernel=3, stride=2, pad=1, use_bias=use_bias)
-    x = prelu(vs, scope + "/res2/prelu", x)
+    if opt.get("bn_in_d"):
+        x = batch_norm(vs, scope + "/res2/batch_norm", x, opt, True)
+    x = activation(vs, scope + "/res2/prelu", x, opt)
     x = conv(vs, scope + "/res2/conv_0", x, channels, opt, kernel=3, stride=1, pad=1, use_bias=use_bias)
     skip = conv(vs, scope + "/skip/conv_0", x_init, channels, opt, kernel=3, stride=2, pad=1, use_bias=use_bias)
     return x + skip

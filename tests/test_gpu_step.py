@@ -299,6 +299,21 @@ def test_sample_with_ema_weights():
     assert set(ref_state) == set(after)
 
 
+@pytest.mark.parametrize("okw,hkw", [
+    (dict(activation="relu"), dict(activation="relu")),
+    (dict(activation="lrelu"), dict(activation="lrelu")),
+    (dict(conv_padding="zero"), dict(conv_padding="zero")),
+    (dict(bn_in_d=True), dict(bn_in_d="true")),
+])
+def test_step_parity_non_default_flags(okw, hkw):
+    """--activation relu / lrelu (BigGAN.py:71-83), --conv_padding zero (TF SAME,
+    ops.py:79-80), --bn_in_d (ops.py:191,296; D then runs once per real / fake batch as in the reference)."""
+    tr = oracle_trainer(64, 8, 64, 4, **okw)
+    gan = hip_model_like(tr, **hkw)
+    batch = RM.synthetic_batch(tr.cfg, 13, 4)
+    _run_parity(tr, gan, batch)
+
+
 def test_extension_32px():
     tr = oracle_trainer(32, 16, 64, 4, extension_32=True)
     gan = hip_model_like(tr)
