@@ -2,6 +2,7 @@
 // statistics, (conditional) batch-norm + PReLU forward/backward, pooling, softmax, small
 // elementwise ops, bias gradient, fused TF-Adam + EMA.  16-byte vector accesses, wave64 shuffle
 // reductions, grid-stride loops capped at 2048 blocks (256 CUs x 8).
+#include <stdlib.h>
 #include "common.h"
 
 namespace bg {
@@ -88,8 +89,13 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(Fn fn, OutT* out, i
 template <int NQ, class Fn, class OutT>
 static void launch_colreduce(Fn fn, OutT* out, int64_t qstride, int64_t rows_per_seg, int nseg, int C,
                              hipStream_t s) {
-    // ~1024 blocks in total, at least 32 rows per block
-    int64_t blocks_per_seg = (1024 + nseg - 1) / nseg;
+    // Every block ends with one atomic per column on the SAME addresses, and those serialise (~0.1 us per
+    // block, measured: 1024 blocks = 105 us whatever the tensor size).  192 blocks x 4 loads in flight per
+    // thread already cover the HBM bandwidth-delay product (268 MB in 55 us = 4.9 TB/s); 128 for < 100 MB.
+    static const int env_blocks = getenv("BG_COLRED_BLOCKS") ? atoi(getenv("BG_COLRED_BLOCKS")) : 0;
+    const int64_t bytes = rows_per_seg * (int64_t)nseg * C * 4;
+    const int target_blocks = env_blocks > 0 ? env_blocks : (bytes > (100ll << 20) ? 192 : 128);
+    int64_t blocks_per_seg = (target_blocks + nseg - 1) / nseg;
     int64_t rpb = (rows_per_seg + blocks_per_seg - 1) / blocks_per_seg;
     if (rpb < 32) rpb = 32;
     blocks_per_seg = (rows_per_seg + rpb - 1) / rpb;

@@ -40,9 +40,11 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const float* __restri
                                                             RgbGeom g, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float wl[];     // [taps][Cin][4] (co padded to 4)
     const int taps = g.k * g.k;
+    // LDS image [tap][co (padded to 4)][Cin]: the 16 lanes of a pixel read 16 consecutive float4 (4 channels each)
+    // of one output channel - conflict-free ds_read_b128 (a [tap][Cin][co] image puts lanes 64 bytes apart: 4-way)
     for (int i = threadIdx.x; i < taps * g.Cin * 4; i += 256) {
-        const int co = i & 3, tc = i >> 2;
-        wl[i] = co < g.Cout ? w[(int64_t)tc * g.Cout + co] : 0.f;
+        const int c = i % g.Cin, tco = i / g.Cin, co = tco & 3, tp = tco >> 2;
+        wl[i] = co < g.Cout ? w[((int64_t)tp * g.Cin + c) * g.Cout + co] : 0.f;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, sub = lane >> 4, cq = (lane & 15) * 4;
@@ -67,14 +69,12 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const float* __restri
                     const float* wt = wl + (kh * g.k + kw) * g.Cin * 4;
                     for (int c = cq; c < g.Cin; c += 64) {
                         const float4 xv = *reinterpret_cast<const float4*>(xp + c);
-                        const float4 w0 = *reinterpret_cast<const float4*>(wt + (c + 0) * 4);
-                        const float4 w1 = *reinterpret_cast<const float4*>(wt + (c + 1) * 4);
-                        const float4 w2 = *reinterpret_cast<const float4*>(wt + (c + 2) * 4);
-                        const float4 w3 = *reinterpret_cast<const float4*>(wt + (c + 3) * 4);
-                        acc[0] += xv.x * w0.x + xv.y * w1.x + xv.z * w2.x + xv.w * w3.x;
-                        acc[1] += xv.x * w0.y + xv.y * w1.y + xv.z * w2.y + xv.w * w3.y;
-                        acc[2] += xv.x * w0.z + xv.y * w1.z + xv.z * w2.z + xv.w * w3.z;
-                        acc[3] += xv.x * w0.w + xv.y * w1.w + xv.z * w2.w + xv.w * w3.w;
+                        const float4 w0 = *reinterpret_cast<const float4*>(wt + c);
+                        const float4 w1 = *reinterpret_cast<const float4*>(wt + g.Cin + c);
+                        const float4 w2 = *reinterpret_cast<const float4*>(wt + 2 * g.Cin + c);
+                        acc[0] += xv.x * w0.x + xv.y * w0.y + xv.z * w0.z + xv.w * w0.w;
+                        acc[1] += xv.x * w1.x + xv.y * w1.y + xv.z * w1.z + xv.w * w1.w;
+                        acc[2] += xv.x * w2.x + xv.y * w2.y + xv.z * w2.z + xv.w * w2.w;
                     }
                 }
             }
@@ -100,9 +100,11 @@ __global__ __launch_bounds__(256) void rgb_conv_dgrad_kernel(const float* __rest
                                                               float* __restrict__ dx, RgbGeom g, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float wl[];     // [taps][Cin][4]
     const int taps = g.k * g.k;
+    // LDS image [tap][co (padded to 4)][Cin]: the 16 lanes of a pixel read 16 consecutive float4 (4 channels each)
+    // of one output channel - conflict-free ds_read_b128 (a [tap][Cin][co] image puts lanes 64 bytes apart: 4-way)
     for (int i = threadIdx.x; i < taps * g.Cin * 4; i += 256) {
-        const int co = i & 3, tc = i >> 2;
-        wl[i] = co < g.Cout ? w[(int64_t)tc * g.Cout + co] : 0.f;
+        const int c = i % g.Cin, tco = i / g.Cin, co = tco & 3, tp = tco >> 2;
+        wl[i] = co < g.Cout ? w[((int64_t)tp * g.Cin + c) * g.Cout + co] : 0.f;
     }
     __syncthreads();
     const int CQ = g.Cin / 4;
@@ -135,21 +137,20 @@ __global__ __launch_bounds__(256) void rgb_conv_dgrad_kernel(const float* __rest
                         if (wi >= 1 && wi <= g.pad) wos[1] = g.pad - wi - kw;
                         else if (wi >= g.W - 1 - g.pad && wi <= g.W - 2) wos[1] = 2 * (g.W - 1) + g.pad - wi - kw;
                     }
-                    const float* wt = wl + ((kh * g.k + kw) * g.Cin + c) * 4;
-                    const float4 w0 = *reinterpret_cast<const float4*>(wt);
-                    const float4 w1 = *reinterpret_cast<const float4*>(wt + 4);
-                    const float4 w2 = *reinterpret_cast<const float4*>(wt + 8);
-                    const float4 w3 = *reinterpret_cast<const float4*>(wt + 12);
+                    const float* wt = wl + (kh * g.k + kw) * g.Cin * 4 + c;       // [tap][co][Cin]
+                    const float4 w0 = *reinterpret_cast<const float4*>(wt);            // co 0, channels c..c+3
+                    const float4 w1 = *reinterpret_cast<const float4*>(wt + g.Cin);
+                    const float4 w2 = *reinterpret_cast<const float4*>(wt + 2 * g.Cin);
                     for (int e = 0; e < 2; ++e) {
                         const int wo = wos[e];
                         if (wo < 0 || wo >= g.W) continue;
                         const float* d = dy + ((b * g.H + ho) * g.W + wo) * g.Cout;
                         float dv[RGB_MAXCO] = {0.f, 0.f, 0.f, 0.f};
                         for (int co = 0; co < g.Cout; ++co) dv[co] = d[co];
-                        acc.x += dv[0] * w0.x + dv[1] * w0.y + dv[2] * w0.z + dv[3] * w0.w;
-                        acc.y += dv[0] * w1.x + dv[1] * w1.y + dv[2] * w1.z + dv[3] * w1.w;
-                        acc.z += dv[0] * w2.x + dv[1] * w2.y + dv[2] * w2.z + dv[3] * w2.w;
-                        acc.w += dv[0] * w3.x + dv[1] * w3.y + dv[2] * w3.z + dv[3] * w3.w;
+                        acc.x += dv[0] * w0.x + dv[1] * w1.x + dv[2] * w2.x;
+                        acc.y += dv[0] * w0.y + dv[1] * w1.y + dv[2] * w2.y;
+                        acc.z += dv[0] * w0.z + dv[1] * w1.z + dv[2] * w2.z;
+                        acc.w += dv[0] * w0.w + dv[1] * w1.w + dv[2] * w2.w;
                     }
                 }
             }
