@@ -538,6 +538,54 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
+// Few outputs, many slabs (3-channel and narrow layers: a 27 x 64 gradient split 768 ways): one thread per
+// output walking all slabs serially is latency-bound (120 us); here 8 z-lanes x 4 loads in flight share
+// each float4 column and combine through LDS (fixed order: deterministic).  n % 4 == 0.
+__global__ __launch_bounds__(256) void slab_reduce_small_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                                int64_t n4, int splitk, int64_t slab) {
+    __shared__ float4 part[8][32];
+    const int tx = threadIdx.x & 31, tz = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + tx;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    if (i < n4) {
+        const float* p = ws + i * 4;
+        int z = tz;
+        for (; z + 24 < splitk; z += 32) {
+            const float4 a = ld4(p + (int64_t)z * slab), b = ld4(p + (int64_t)(z + 8) * slab);
+            const float4 c = ld4(p + (int64_t)(z + 16) * slab), d = ld4(p + (int64_t)(z + 24) * slab);
+            add4(s0, a);
+            add4(s1, b);
+            add4(s2, c);
+            add4(s3, d);
+        }
+        for (; z < splitk; z += 8) add4(s0, ld4(p + (int64_t)z * slab));
+        add4(s0, s1);
+        add4(s2, s3);
+        add4(s0, s2);
+    }
+    part[tz][tx] = s0;
+    __syncthreads();
+    if (tz == 0 && i < n4) {
+        float4 s = part[0][tx];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) add4(s, part[l][tx]);
+        *reinterpret_cast<float4*>(out + i * 4) = s;
+    }
+}
+
+static void launch_slab_reduce(const float* ws, float* out, int64_t n, int splitk, int64_t slab, hipStream_t s) {
+    if ((n & 3) == 0 && (n >> 2) <= 16384 && splitk >= 16) {
+        const int64_t n4 = n >> 2;
+        hipLaunchKernelGGL(slab_reduce_small_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, s, ws, out, n4,
+                           splitk, slab);
+        return;
+    }
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, out, n, splitk, slab);
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -757,11 +805,7 @@ static int launch_tn(TNParams& p, int mode, bool vec, float* final_out, void* ws
         launch_tn_inst<1, 1, 4, 1>(p, mode, vec, grid, s);     // 128 x 32
     BG_LAUNCH_CHECK();
     if (pl.splitk > 1) {
-        int blocks = (int)((total / 4 + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(ws),
-                           final_out, total, pl.splitk, total);
+        launch_slab_reduce(reinterpret_cast<const float*>(ws), final_out, total, pl.splitk, total, s);
         BG_LAUNCH_CHECK();
     }
     return BG_OK;
