@@ -601,11 +601,23 @@ static NNPlan plan_nn(int64_t M, int N, int zdim, int niter_min, bool allow_spli
     NNPlan pl;
     pl.splitk = 1;
     const int64_t want = 384;
+    // narrow outputs with a long K and a handful of tiles (low-rank Gram of the cond-BN kernels: 32 x 32 x 1024
+    // in ONE block = 64 serial K-steps = 44 us): split K
+    auto narrow_split = [&](int bm, int bn) {
+        const int64_t b = blocks(bm, bn);
+        if (!allow_split || b >= 64 || niter_min < 16) return;
+        int sk = (int)((128 + b - 1) / b);
+        if (sk > niter_min / 4) sk = niter_min / 4;
+        if (sk > 32) sk = 32;
+        if (sk > 1) pl.splitk = sk;
+    };
     if (N <= 32) {
         pl.bm = 128; pl.bn = 32;
+        narrow_split(128, 32);
     } else if (N <= 64) {
         pl.bn = 64;
         pl.bm = blocks(128, 64) >= want ? 128 : 64;
+        narrow_split(pl.bm, 64);
     } else if (blocks(128, 128) >= want) {
         pl.bm = 128; pl.bn = 128;
     } else if (blocks(128, 64) >= want) {

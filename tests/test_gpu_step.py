@@ -40,6 +40,21 @@ def _noise_driven(name):
     return name.endswith("self_attention/f_conv/bias")
 
 
+def _state_err(hip_v, ref_v, g_ref=None):
+    """Relative L2 error of a post-step tensor.  TF-Adam with beta1 = 0 moves an element by
+    -lr * g / (|g| + eps): the SIGN of g alone.  Where the exact gradient element is ~0 relative to its
+    tensor (|g| < 1e-3 max|g|) that sign is fp32 rounding noise on every platform, so those elements are
+    left out of the comparison (they are compared as gradients, by norm, in _check_grads)."""
+    a = np.asarray(hip_v, np.float64).ravel()
+    b = np.asarray(ref_v, np.float64).ravel()
+    if g_ref is not None:
+        g = np.abs(np.asarray(g_ref, np.float64).ravel())
+        keep = g > 1e-3 * max(g.max(), 1e-300)
+        if keep.any():
+            a, b = a[keep], b[keep]
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
 def _grad_err(a, b, extra_scale=0.0):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
@@ -134,7 +149,7 @@ def _run_parity(tr, gan, batch, check_state=True):
         return
 
     # ---------------- one full iteration: D update then G update ----------------
-    tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], **okw_d)
+    rd = tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], **okw_d)
     gan.d_step(real, z_d, a_r, a_fd, **hkw_d)
     after = tr.vs.export()
     hip1 = gan.store.export_arrays()
@@ -147,7 +162,8 @@ def _run_parity(tr, gan, batch, check_state=True):
             assert np.array_equal(hip1[k], hip0[k]), ("must not change in the D step", k)
         else:
             assert not np.array_equal(hip1[k], hip0[k]), ("must change in the D step", k)
-            e = rel_err(hip1[k], after[k])
+            gk = rd["grads"].get(k)
+            e = _state_err(hip1[k], after[k], None if gk is None else gk.numpy())
             assert e < STATE_TOL, ("d-step state", k, e)
     ro = tr.g_step(batch["z_g"], batch["aug_fake_g"], **okw_g)
     ho = gan.g_step(B, z_g, a_fg, **hkw_g)
@@ -163,12 +179,14 @@ def _run_parity(tr, gan, batch, check_state=True):
             assert np.array_equal(hip2[k], hip1[k]), ("must not change in the G step", k)
         else:
             assert not np.array_equal(hip2[k], hip1[k]), ("must change in the G step", k)
-        e = rel_err(hip2[k], after2[k]) if np.linalg.norm(after2[k]) > 0 else 0.0
+        gk = ro["grads"].get(k)
+        e = _state_err(hip2[k], after2[k], None if gk is None else gk.numpy()) if np.linalg.norm(after2[k]) > 0 else 0.0
         assert e < STATE_TOL, ("g-step state", k, e)
     for k, s_ in tr.ema.items():
         if _noise_driven(k):
             continue
-        e = rel_err(t2n(gan.g_arena.view(gan.g_arena.ema, k)), s_.numpy())
+        gk = ro["grads"].get(k)
+        e = _state_err(t2n(gan.g_arena.view(gan.g_arena.ema, k)), s_.numpy(), None if gk is None else gk.numpy())
         assert e < STATE_TOL, ("ema", k, e)
 
 
