@@ -185,7 +185,7 @@ def main():
             "--da_policy", a.da_policy, "--g_regularization", a.g_regularization, "--n_labels", str(a.n_labels)]
     args = M.parse_args(argv, make_dirs=False)
     bf16 = a.workload in BF16_WORKLOADS
-    hip.lib().bg_set_gemm_compute(1 if bf16 else 0)
+    hip.lib().bg_set_gemm_compute(2 if bf16 else 0)     # 2: convs + the large regulariser GEMMs
     peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
     gan = model.BigGAN(args, device="cuda", store=S.VariableStore("cuda", seed=42)).build_model()
     real = gan.synthetic_batch(B)

@@ -694,7 +694,7 @@ static size_t nn_workspace_bytes(int64_t M, int N, int zdim, int niter_min, int6
 static int launch_nn(NNParams& p, int mode, bool bt, bool mirror, bool vec, int zdim, int niter_min,
                      int64_t out_elems, bool out_dense, void* ws, size_t ws_bytes, hipStream_t s,
                      bool allow_bf16 = false) {
-    const bool bf16 = allow_bf16 && g_gemm_compute.load() == 1;
+    const bool bf16 = allow_bf16 && g_gemm_compute.load() >= 1;
     NNPlan pl = plan_nn(p.M, p.N, zdim, niter_min, out_dense && ws != nullptr);
     if (pl.splitk > 1 && ws_bytes < (size_t)pl.splitk * out_elems * sizeof(float)) {
         pl = plan_nn(p.M, p.N, zdim, niter_min, false);
@@ -709,9 +709,9 @@ static int launch_nn(NNParams& p, int mode, bool bt, bool mirror, bool vec, int 
     else if (mode == GATHER_TCONV)
         launch_nn_tile<true, GATHER_TCONV, false>(p, pl, vec, bf16, zdim, s);
     else if (bt)
-        launch_nn_tile<true, GATHER_PLAIN, false>(p, pl, vec, false, zdim, s);
+        launch_nn_tile<true, GATHER_PLAIN, false>(p, pl, vec, bf16, zdim, s);
     else
-        launch_nn_tile<false, GATHER_PLAIN, false>(p, pl, vec, false, zdim, s);
+        launch_nn_tile<false, GATHER_PLAIN, false>(p, pl, vec, bf16, zdim, s);
     BG_LAUNCH_CHECK();
     if (pl.splitk > 1) {
         int blocks = (int)((out_elems + 255) / 256);
@@ -773,7 +773,7 @@ static void launch_tn_inst(const TNParams& p, int mode, bool vec, dim3 grid, hip
 // out must be a dense [batch][Mf][Cb] block when split-K is used
 static int launch_tn(TNParams& p, int mode, bool vec, float* final_out, void* ws, size_t ws_bytes, hipStream_t s,
                      bool allow_bf16 = false) {
-    const bool bf16 = allow_bf16 && vec && mode == GATHER_CONV && g_gemm_compute.load() == 1;
+    const bool bf16 = allow_bf16 && vec && g_gemm_compute.load() >= 1;
     TNPlan pl = plan_tn(p.Mf, p.Cb, p.batch, p.M);
     const int64_t total = (int64_t)p.batch * p.Mf * p.Cb;
     const bool dense = (p.out_ld == p.Cb) && (p.batch == 1 || p.strideC == (int64_t)p.Mf * p.Cb);
@@ -800,13 +800,20 @@ static int launch_tn(TNParams& p, int mode, bool vec, float* final_out, void* ws
         p.zfold = p.splitk;
         grid = dim3(p.tiles_m * p.tiles_n * p.splitk, 1, 1);
     }
-    if (bf16 && pl.bn >= 64) {
+    if (bf16 && pl.bn >= 64 && mode == GATHER_CONV) {
         if (pl.bm == 128 && pl.bn == 128)
             hipLaunchKernelGGL((tn_kernel_bf16<2, 2, GATHER_CONV>), grid, dim3(256), 0, s, p);
         else if (pl.bm == 128 && pl.bn == 64)
             hipLaunchKernelGGL((tn_kernel_bf16<2, 1, GATHER_CONV>), grid, dim3(256), 0, s, p);
         else
             hipLaunchKernelGGL((tn_kernel_bf16<1, 1, GATHER_CONV>), grid, dim3(256), 0, s, p);
+    } else if (bf16 && pl.bn >= 64) {
+        if (pl.bm == 128 && pl.bn == 128)
+            hipLaunchKernelGGL((tn_kernel_bf16<2, 2, GATHER_PLAIN>), grid, dim3(256), 0, s, p);
+        else if (pl.bm == 128 && pl.bn == 64)
+            hipLaunchKernelGGL((tn_kernel_bf16<2, 1, GATHER_PLAIN>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((tn_kernel_bf16<1, 1, GATHER_PLAIN>), grid, dim3(256), 0, s, p);
     } else if (pl.bm == 128 && pl.bn == 128)
         launch_tn_inst<2, 2, 2, 2>(p, mode, vec, grid, s);
     else if (pl.bm == 128 && pl.bn == 64)
@@ -933,7 +940,7 @@ using namespace bg;
 
 extern "C" {
 
-void bg_set_gemm_compute(int mode) { g_gemm_compute.store(mode == 1 ? 1 : 0); }
+void bg_set_gemm_compute(int mode) { g_gemm_compute.store(mode == 1 || mode == 2 ? mode : 0); }
 int bg_get_gemm_compute(void) { return g_gemm_compute.load(); }
 
 size_t bg_conv2d_fwd_workspace_bytes(const BgConvDesc* d) {
@@ -1074,6 +1081,12 @@ size_t bg_gemm_workspace_bytes(const BgGemmDesc* d) {
     return nn_workspace_bytes(d->M, d->N, 1, kc_of(d->K), (int64_t)d->M * d->N);
 }
 
+// compute mode 2: the large plain GEMMs too (regulariser Grams and their gradients: batch-independent
+// work that is 20 % of the step at ch = 96, batch 32); small / skinny ones (dense layers, cond-BN FCs) stay fp32
+static bool gemm_wants_bf16(const BgGemmDesc* d) {
+    return g_gemm_compute.load() == 2 && d->M >= 128 && d->N >= 128 && d->K >= 128;
+}
+
 int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bias, const float* alpha_dev,
             float* C, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     BG_REQUIRE(d != nullptr, "null BgGemmDesc");
@@ -1097,7 +1110,7 @@ int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bi
         ProfScope prof(as_stream(stream), flops, tag.s);
         const bool dense = d->ldc == d->N && d->batch == 1;
         return launch_nn(p, GATHER_PLAIN, d->transB != 0, false, vec, d->batch, kc_of(d->K), (int64_t)d->M * d->N,
-                         dense, dense ? ws : nullptr, ws_bytes, as_stream(stream));
+                         dense, dense ? ws : nullptr, ws_bytes, as_stream(stream), gemm_wants_bf16(d));
     }
     BG_REQUIRE(!d->transB, "bg_gemm: transA && transB unsupported");
     BG_REQUIRE(bias == nullptr && !accumulate, "bg_gemm: transA path has no bias / accumulate");
@@ -1113,7 +1126,7 @@ int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bi
     const bool vec = (d->M % 4 == 0) && (d->lda % 4 == 0) && (d->strideA % 4 == 0) && aligned16(A) &&
                      (d->N % 4 == 0) && (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
     ProfScope prof(as_stream(stream), flops, tag.s);
-    return launch_tn(p, GATHER_PLAIN, vec, C, ws, ws_bytes, as_stream(stream));
+    return launch_tn(p, GATHER_PLAIN, vec, C, ws, ws_bytes, as_stream(stream), gemm_wants_bf16(d));
 }
 
 }  // extern "C"

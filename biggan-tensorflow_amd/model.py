@@ -369,9 +369,35 @@ class BigGAN(GANBase):
                          if w.startswith(group + "/") and w in self.store.arenas[group].offsets]
                 for i in range(0, len(pairs), 256):
                     self.sn_batches.setdefault(group, []).append(Fn.SnBatch(pairs[i:i + 256]))
+        self.reg_owner = self._shard_regularisers()
         self.counter = 0
         self.built = True
         return self
+
+    def _shard_regularisers(self):
+        """The ortho-cosine terms depend on the weights only, so under data parallelism every rank would
+        repeat the same 2 x 229 GFLOP (config 2) of Gram work.  Instead each kernel's term is evaluated
+        on ONE rank (longest-processing-time assignment by GEMM cost) and the SUM all-reduce of the
+        gradient arena delivers it everywhere."""
+        if self.world == 1:
+            return None
+        cost = {}
+        for name, shape in self.store.reg_shapes.items():
+            c = shape[-1]
+            rows = 1
+            for d in shape[:-1]:
+                rows *= d
+            cost[name] = rows * rows * c if 2 * rows <= c else rows * c * c
+        load = [0] * self.world
+        owner = {}
+        for name in sorted(cost, key=lambda k: (-cost[k], k)):
+            r = min(range(self.world), key=lambda i: (load[i], i))
+            owner[name] = r
+            load[r] += cost[name]
+        return owner
+
+    def _begin_run(self):
+        ops.begin_run(self._reduce_fn(), self.world, self.rank, getattr(self, "reg_owner", None))
 
     def _sn_prefetch(self, group, x):
         if x.is_cuda:
@@ -431,7 +457,7 @@ class BigGAN(GANBase):
         real half when n_labels > 0, BigGAN.py:853).  G runs without a backward graph (d_loss is minimised
         over d_vars only); real and fake go through D as one batch."""
         B = real.shape[0]
-        ops.begin_run(self._reduce_fn(), self.world)
+        self._begin_run()
         if z is None:
             z = self.sample_z(B)
         if self.acgan and cls_z is None:
@@ -501,7 +527,7 @@ class BigGAN(GANBase):
 
     def g_forward(self, B, z=None, draws_fake=None, cls_z=None):
         """BigGAN.py:896-898: -mean(D(aug(G(z)))) + flood (+ label loss, BigGAN.py:894) + regularisation losses."""
-        ops.begin_run(self._reduce_fn(), self.world)
+        self._begin_run()
         if z is None:
             z = self.sample_z(B)
         if self.acgan and cls_z is None:
@@ -530,17 +556,17 @@ class BigGAN(GANBase):
                 out = self.g_forward(B, self._per_virtual_batch(k, z), self._per_virtual_batch(k, draws_fake), cls_z)
                 roots = [out["g_adv"]] + out["regs"]
                 ones = torch.ones(1, dtype=torch.float32, device=self.device)
-                # regularisation terms are replicated on every rank: weight them 1/world so that the
-                # SUM all-reduce of the flat gradient arena yields the single-process gradient
-                rw = ones if self.world == 1 else ones / self.world
-                torch.autograd.backward(roots, [ones] + [rw] * len(out["regs"]))
+                # each regularisation term is evaluated on exactly one rank (_shard_regularisers): weight 1,
+                # the SUM all-reduce of the flat gradient arena then yields the single-process gradient
+                torch.autograd.backward(roots, [ones] * len(roots))
                 self._sn_backward("generator")
                 if out["regs"]:
-                    out["g_reg"] = torch.stack([r.detach() for r in out["regs"]]).sum()
-                    out["g_loss"] = out["g_adv"].detach() + out["g_reg"]
+                    out["g_reg"] = torch.stack([r.detach() for r in out["regs"]]).sum().reshape(1)
                 else:
                     out["g_reg"] = torch.zeros(1, device=self.device)
-                    out["g_loss"] = out["g_adv"].detach()
+                if self.world > 1 and self.g_regularization_method != 'none':
+                    self._reduce_fn()(out["g_reg"])                 # reported value: sum over the owners
+                out["g_loss"] = out["g_adv"].detach() + out["g_reg"]
                 outs.append(out)
         finally:
             self._set_requires_grad(self.d_vars, True)

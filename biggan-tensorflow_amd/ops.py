@@ -31,12 +31,14 @@ class _Run:
         self.reg_seen = set()
         self.reduce_fn = None    # in-place SUM all-reduce of a small fp32 tensor across DP ranks
         self.world = 1
+        self.rank = 0
+        self.reg_owner = None    # data parallel: variable name -> rank that evaluates its regulariser
 
 
 _run = _Run()
 
 
-def begin_run(reduce_fn=None, world=1):
+def begin_run(reduce_fn=None, world=1, rank=0, reg_owner=None):
     """Start of one ``sess.run``: forget cached spectral norms and regularisation losses."""
     _run.sn_cache = {}
     _run.sn_prefetched = set()
@@ -44,6 +46,8 @@ def begin_run(reduce_fn=None, world=1):
     _run.reg_seen = set()
     _run.reduce_fn = reduce_fn
     _run.world = world
+    _run.rank = rank
+    _run.reg_owner = reg_owner
 
 
 def sn_prefetch(batch):
@@ -76,8 +80,11 @@ def _regularize(w, regularizer):
     if w.bg_name in _run.reg_seen:
         return
     _run.reg_seen.add(w.bg_name)
+    S.default_store().reg_shapes.setdefault(w.bg_name, tuple(int(d) for d in w.shape))
     if _is_meta(w) or not w.is_cuda:
         return
+    if _run.reg_owner is not None and _run.reg_owner.get(w.bg_name, 0) != _run.rank:
+        return                   # another rank evaluates this (batch-independent) term; gradients meet in the all-reduce
     _run.reg_losses.append(regularizer(w))
 
 

@@ -91,6 +91,7 @@ class VariableStore:
         self._counts = {}                    # scope path -> times opened (for default_name uniquifying)
         self.frozen = False
         self.sn_pairs = OrderedDict()        # spectrally-normalised weight name -> name of its u vector
+        self.reg_shapes = OrderedDict()      # regularised kernel name -> shape (tf regularisation-loss collection)
 
     def register_sn(self, w_name, u_name):
         self.sn_pairs.setdefault(w_name, u_name)

@@ -51,7 +51,8 @@ typedef struct BgConvDesc {
 /* Compute precision of the conv / transposed-conv entry points (process-wide):
  *   0 = fp32 MFMA (default; the reference's precision, ops.py:14)
  *   1 = bf16 MFMA with fp32 accumulation: operands are rounded to bf16 (RNE) while they are staged
- *       into LDS; tensors in HBM, outputs, dense layers, attention and every other kernel stay fp32. */
+ *       into LDS; tensors in HBM, outputs, dense layers, attention and every other kernel stay fp32.
+ *   2 = 1 + bg_gemm launches with M, N, K >= 128 (the regulariser's Gram matrices and their gradients). */
 void bg_set_gemm_compute(int mode);
 int  bg_get_gemm_compute(void);
 

@@ -73,6 +73,42 @@ def test_deconv_bf16(bf16_mode, N, H, Cin, Cout, k, s):
     assert min(e) > 1e-5, ("bf16 path does not seem to be active", e)
 
 
+def test_bf16_mode2_regulariser_and_large_gemm():
+    """bg_set_gemm_compute(2): the large plain GEMMs (Gram matrices of the ortho-cosine regulariser and
+    their gradients) run on the bf16 MFMA too; loss <= 2e-2, gradient <= 3e-2 relative to float64."""
+    import biggan_tensorflow_amd  # noqa: F401
+    from biggan_tensorflow_amd import functional as Fn, hip
+    from oracle import ref_ops as R
+    L = hip.lib()
+    L.bg_set_gemm_compute(2)
+    try:
+        assert L.bg_get_gemm_compute() == 2
+        rng = np.random.default_rng(5)
+        for shape in [(3, 3, 256, 256), (4, 4, 128, 192), (184, 1024)]:
+            w = rng.standard_normal(shape) * 0.05
+            wt = torch.tensor(w, requires_grad=True)
+            ref = R.ortho_reg_loss(wt, 1e-4, "ortho_cosine") if shape[-1] <= 256 else R.ortho_cosine_closed_form(wt, 1e-4)
+            ref.backward()
+            wc = cu(w, True)
+            loss = Fn.OrthoCosineRegFn.apply(wc, 1e-4)
+            loss.backward()
+            assert abs(loss.item() - ref.item()) <= 2e-2 * abs(ref.item()), (shape, loss.item(), ref.item())
+            e = rel_err(t2n(wc.grad), wt.grad.numpy())
+            assert 1e-6 < e < 3e-2, (shape, e)
+        # plain GEMM, both kernels (NN and TN)
+        A, B = rng.standard_normal((512, 384)), rng.standard_normal((384, 256))
+        C = torch.empty(512, 256, device="cuda")
+        Fn.gemm(cu(A), cu(B), C, 512, 256, 384, 384, 256, 256)
+        assert 1e-5 < rel_err(t2n(C), A @ B) < 1e-2
+        C2 = torch.empty(384, 256, device="cuda")
+        A2 = rng.standard_normal((512, 384))
+        B2 = rng.standard_normal((512, 256))
+        Fn.gemm(cu(A2), cu(B2), C2, 384, 256, 512, 384, 256, 256, transA=True)
+        assert 1e-5 < rel_err(t2n(C2), A2.T @ B2) < 1e-2
+    finally:
+        L.bg_set_gemm_compute(0)
+
+
 def test_bf16_step_losses_close_to_fp32(bf16_mode):
     """Whole D+G iteration in bf16-compute mode: losses within 2e-2 relative of the float64 oracle
     (bf16 tolerance stated separately from the fp32 gate)."""

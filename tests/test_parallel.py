@@ -42,7 +42,14 @@ def _worker(rank, world, port, q):
     parallel.broadcast_flat(p, src=0)
     ok3 = p.tolist() == [0.0] * 5
     lo, hi = parallel.shard_batch(64, rank, world)
-    q.put((rank, ok1, ok2, ok3, lo, hi))
+    # regulariser sharding: identical owner maps on all ranks, every kernel owned once, loads balanced
+    from biggan_tensorflow_amd import main as M, model, scope as S
+    g = model.BigGAN(M.parse_args(["--gan_type", "hinge", "--img_size", "128", "--ch", "16"], make_dirs=False),
+                     device="cpu", store=S.VariableStore("cpu")).build_model()
+    owner = g.reg_owner
+    ok4 = (g.world == world and g.rank == rank and owner is not None and
+           set(owner) == set(g.store.reg_shapes) and len(owner) == 42 and set(owner.values()) == set(range(world)))
+    q.put((rank, ok1, ok2, ok3, lo, hi, ok4, sorted(owner.items())))
     dist.destroy_process_group()
 
 
@@ -54,11 +61,12 @@ def test_gloo_world2_allreduce_and_sharding():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
+    res = sorted(q.get(timeout=240) for _ in range(world))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert res == [(0, True, True, True, 0, 32), (1, True, True, True, 32, 64)]
+    assert [r[:7] for r in res] == [(0, True, True, True, 0, 32, True), (1, True, True, True, 32, 64, True)]
+    assert res[0][7] == res[1][7]                      # the same owner map on every rank
 
 
 def test_shard_batch_rejects_ragged():
