@@ -685,9 +685,21 @@ __device__ __forceinline__ void sn_colsum_body(const float* __restrict__ w, cons
     const int r1 = min(rows, r0 + rows_per_block);
     const int c = cb * EW_BLOCK + threadIdx.x;
     if (c >= cols) return;
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += vraw[r] * w[(int64_t)r * cols + c];
-    atomicAdd(&uraw[c], (double)s);
+    // 8 rows' loads in flight per thread (one dependent round trip per row otherwise)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* wp = w + c;
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = wp[(int64_t)(r + u) * cols];
+        s0 += vraw[r] * a[0] + vraw[r + 4] * a[4];
+        s1 += vraw[r + 1] * a[1] + vraw[r + 5] * a[5];
+        s2 += vraw[r + 2] * a[2] + vraw[r + 6] * a[6];
+        s3 += vraw[r + 3] * a[3] + vraw[r + 7] * a[7];
+    }
+    for (; r < r1; ++r) s0 += vraw[r] * wp[(int64_t)r * cols];
+    atomicAdd(&uraw[c], (double)((s0 + s1) + (s2 + s3)));
 }
 
 // split of the [rows, cols] column reduction into (column block, row chunk) work units
