@@ -72,6 +72,12 @@ def _bias_grad(dy2d, out):
 class Conv2dFn(Function):
     """tf.pad(REFLECT)+tf.nn.conv2d(VALID)+bias_add (ops.py:82,94-98) / zero 'SAME'."""
 
+    # The direct kernels for <= 4 INPUT channels (bg_thinconv_*) are correct but, as measured in round 1
+    # (128 x 128 x 3 -> 64, stride 2, batch 128: fwd 251 us / dgrad 1489 us / wgrad 210 us), slower than the
+    # padded implicit GEMM (130 / 411 / 112 us): one pixel per thread iteration leaves them latency-bound.
+    # Off until they process several pixels per iteration; tests switch them on to keep them covered.
+    use_thin = False
+
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad_lo, Ho, Wo, pad_mode):
         x = _c(x)
@@ -83,8 +89,11 @@ class Conv2dFn(Function):
         y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         L = lib()
         ctx.rgb = bool(L.bg_rgbconv_supported(d))      # <= 3 output channels: direct HBM-bound kernels
+        ctx.thin = Conv2dFn.use_thin and (not ctx.rgb) and bool(L.bg_thinconv_supported(d))
         if ctx.rgb:
             check(L.bg_rgbconv_fwd(d, f32(x), f32(w), f32(bias), f32(y), 0, stream()))
+        elif ctx.thin:
+            check(L.bg_thinconv_fwd(d, f32(x), f32(w), f32(bias), f32(y), stream()))
         else:
             ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, d, x.device)
             check(L.bg_conv2d_fwd(d, f32(x), f32(w), f32(bias), None, f32(y), 0, f32(ws), nb, stream()))
@@ -102,6 +111,8 @@ class Conv2dFn(Function):
             dx = torch.empty_like(x)
             if ctx.rgb:
                 check(L.bg_rgbconv_dgrad(d, f32(dy), f32(w), f32(dx), 0, stream()))
+            elif ctx.thin:
+                check(L.bg_thinconv_dgrad(d, f32(dy), f32(w), f32(dx), stream()))
             else:
                 ws, nb = hip.scratch(L.bg_conv2d_dgrad_workspace_bytes, d, x.device)
                 check(L.bg_conv2d_dgrad(d, f32(dy), f32(w), None, f32(dx), 0, f32(ws), nb, stream()))
@@ -111,6 +122,11 @@ class Conv2dFn(Function):
                 nb = L.bg_rgbconv_wgrad_workspace_bytes(d)
                 ws = workspace(nb, x.device)
                 check(L.bg_rgbconv_wgrad(d, f32(x), f32(dy), f32(out), f32(ws), nb, stream()))
+                return
+            if ctx.thin:
+                nb = L.bg_thinconv_wgrad_workspace_bytes(d)
+                ws = workspace(nb, x.device)
+                check(L.bg_thinconv_wgrad(d, f32(x), f32(dy), f32(out), f32(ws), nb, stream()))
                 return
             nb = L.bg_conv2d_wgrad_workspace_bytes(d)
             ws = workspace(nb, x.device)
