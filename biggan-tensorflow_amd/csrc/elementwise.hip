@@ -1240,7 +1240,8 @@ int bg_spectral_norm_batch_fwd(const BgSnItem* items_dev, int n_items, void* ws,
     BG_LAUNCH_CHECK();
     hipLaunchKernelGGL(sn_batch_finalize_kernel, dim3(n_items), dim3(EW_BLOCK), 0, s, items_dev, w8);
     BG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sn_batch_normalize_kernel, dim3(GX, n_items), dim3(EW_BLOCK), 0, s, items_dev, w8);
+    // streaming pass: the largest kernels (85 MB at ch = 96) need more than 128 blocks to pull full bandwidth
+    hipLaunchKernelGGL(sn_batch_normalize_kernel, dim3(4 * GX, n_items), dim3(EW_BLOCK), 0, s, items_dev, w8);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }
@@ -1259,9 +1260,9 @@ int bg_spectral_norm_batch_bwd(const BgSnItem* items_dev, int n_items, const uin
         return BG_ERR_LAUNCH;
     }
     double* dots = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL(sn_batch_dot_kernel, dim3(64, n_items), dim3(EW_BLOCK), 0, s, items_dev, dots, en);
+    hipLaunchKernelGGL(sn_batch_dot_kernel, dim3(256, n_items), dim3(EW_BLOCK), 0, s, items_dev, dots, en);
     BG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sn_batch_bwd_kernel, dim3(128, n_items), dim3(EW_BLOCK), 0, s, items_dev, dots, en, acc);
+    hipLaunchKernelGGL(sn_batch_bwd_kernel, dim3(512, n_items), dim3(EW_BLOCK), 0, s, items_dev, dots, en, acc);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }
