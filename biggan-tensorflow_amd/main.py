@@ -81,7 +81,12 @@ def main(argv=None):
     args = parse_args(argv)
     if args is None:
         exit()
+    import torch
+    from . import parallel
     from .model import BigGAN
+    rank, world, local = parallel.init_from_env()        # torchrun: one process per GPU, RCCL
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % torch.cuda.device_count())
     gan = BigGAN(args)
     gan.build_model()
     if args.phase == 'train':

@@ -605,18 +605,39 @@ class BigGAN(GANBase):
         return torch.rand(B, self.img_size, self.img_size, self.c_dim, device=self.device,
                           generator=self.gen) * 2.0 - 1.0
 
-    def train(self, data_fn=None, iterations=None):
-        """BigGAN.py:1015-1118 training loop (synthetic data unless ``data_fn`` is given)."""
+    def train(self, data_fn=None, iterations=None, resume=True):
+        """BigGAN.py:1015-1118 training loop (synthetic data unless ``data_fn`` is given): resume from the
+        latest checkpoint of ``checkpoint_dir`` if there is one, print the losses every iteration, save
+        every ``save_freq`` iterations of an epoch (rank 0 writes; replicas are identical)."""
+        could_load, checkpoint_counter = (self.load(self.checkpoint_dir) if resume else (False, 0))
+        if could_load:
+            start_epoch = int(checkpoint_counter / self.iterations_per_epoch)
+            start_batch_id = checkpoint_counter - start_epoch * self.iterations_per_epoch
+            print(" [*] Load SUCCESS")
+        else:
+            start_epoch, start_batch_id = 0, 0
+            if resume:
+                print(" [!] Load failed...")
         start_time = time.time()
-        n = iterations if iterations is not None else self.epoch * self.iterations_per_epoch
-        for _ in range(n):
-            real = data_fn() if data_fn is not None else self.synthetic_batch()
-            losses = self.train_step(real)
-            vals = {k: float(v.item()) for k, v in losses.items()}
-            print_str = "Step: %5d, time: %4.4f" % (self.counter, time.time() - start_time)   # BigGAN.py:1109-1116
-            for name, val in vals.items():
-                print_str += ", " + name + ": %.4f" % val
-            print(print_str, flush=True)
+        done = 0
+        for epoch in range(start_epoch, self.epoch):
+            for idx in range(start_batch_id, self.iterations_per_epoch):
+                if iterations is not None and done >= iterations:
+                    return
+                real = data_fn() if data_fn is not None else self.synthetic_batch()
+                losses = self.train_step(real)
+                done += 1
+                vals = {k: float(v.item()) for k, v in losses.items()}
+                print_str = "Step: %5d, time: %4.4f" % (self.counter, time.time() - start_time)   # BigGAN.py:1109-1116
+                for name, val in vals.items():
+                    print_str += ", " + name + ": %.4f" % val
+                if self.rank == 0:
+                    print(print_str, flush=True)
+                if (idx + 1) % self.save_freq == 0 and self.rank == 0:                # BigGAN.py:1121-1122
+                    self.save(self.checkpoint_dir, self.counter)
+            start_batch_id = 0                                                         # BigGAN.py:1164-1166
+            if self.rank == 0:
+                self.save(self.checkpoint_dir, self.counter)
 
     # ---- sampling with the EMA weights (BigGAN.py:963-971) ------------------------------------
     def sample(self, z=None, cls_z=None, B=None, use_ema=True):

@@ -339,6 +339,29 @@ def test_extension_32px():
     _run_parity(tr, gan, batch)
 
 
+def test_train_loop_checkpoints_and_resumes(tmp_path):
+    """BigGAN.train (BigGAN.py:1015-1243): saves every save_freq iterations and at the end of an epoch, a new
+    process picks the latest checkpoint up and continues from its counter with identical state."""
+    from tests.common import make_args
+    from biggan_tensorflow_amd import model, scope as S
+    kw = dict(img_size=64, ch=8, batch_size=2, z_dim=64, iteration=4, epoch=1, save_freq=2,
+              checkpoint_dir=str(tmp_path))
+    gan = model.BigGAN(make_args(**kw), store=S.VariableStore("cuda")).build_model()
+    gan.train()
+    assert gan.counter == 4
+    files = sorted(p.name for p in (tmp_path / gan.model_dir).iterdir())
+    assert files == ["BigGAN.model-2.safetensors", "BigGAN.model-4.safetensors", "checkpoint"], files
+    kw["epoch"] = 2
+    gan2 = model.BigGAN(make_args(**kw), store=S.VariableStore("cuda", seed=7)).build_model()   # different init
+    ok, counter = gan2.load(str(tmp_path))
+    assert ok and counter == 4
+    for k, v in gan.state_tensors().items():
+        assert torch.equal(v, gan2.state_tensors()[k]), k
+    gan2.train()                                   # resumes: epoch 1 of 2, iterations 5..8
+    assert gan2.counter == 8 and (gan2.d_arena.step, gan2.g_arena.step) == (8, 8)
+    assert (tmp_path / gan.model_dir / "BigGAN.model-8.safetensors").exists()
+
+
 def test_train_loop_runs_and_loss_is_finite():
     from tests.common import make_args
     from biggan_tensorflow_amd import model, scope as S
