@@ -953,6 +953,7 @@ int bg_conv2d_fwd(const BgConvDesc* d, const float* x, const float* w, const flo
                   float* y, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_conv(d);
     if (rc) return rc;
+    BG_REQUIRE(x && w && y, "bg_conv2d_fwd: null tensor pointer");
     NNParams p;
     conv_fwd_params(d, p);
     p.A = x; p.B = w; p.bias = bias; p.alpha = alpha_dev; p.out = y; p.accumulate = accumulate;
@@ -974,6 +975,7 @@ int bg_conv2d_dgrad(const BgConvDesc* d, const float* dy, const float* w, const 
                     int accumulate, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_conv(d);
     if (rc) return rc;
+    BG_REQUIRE(dy && w && dx, "bg_conv2d_dgrad: null tensor pointer");
     BG_REQUIRE(d->H % d->stride == 0 && d->W % d->stride == 0, "conv dgrad: H,W must be multiples of stride");
     NNParams p;
     conv_dgrad_params(d, p);
@@ -994,6 +996,7 @@ int bg_conv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, float*
                     void* stream) {
     int rc = check_conv(d);
     if (rc) return rc;
+    BG_REQUIRE(x && dy && dw, "bg_conv2d_wgrad: null tensor pointer");
     TNParams p;
     memset(&p, 0, sizeof(p));
     p.A = x; p.Bv = dy;
@@ -1019,6 +1022,7 @@ int bg_deconv2d_fwd(const BgConvDesc* d, const float* x, const float* w, const f
                     float* y, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_deconv(d);
     if (rc) return rc;
+    BG_REQUIRE(x && w && y, "bg_deconv2d_fwd: null tensor pointer");
     NNParams p;
     deconv_fwd_params(d, p);
     p.A = x; p.B = w; p.bias = bias; p.alpha = alpha_dev; p.out = y; p.accumulate = accumulate;
@@ -1039,6 +1043,7 @@ int bg_deconv2d_dgrad(const BgConvDesc* d, const float* dy, const float* w, cons
                       int accumulate, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_deconv(d);
     if (rc) return rc;
+    BG_REQUIRE(dy && w && dx, "bg_deconv2d_dgrad: null tensor pointer");
     NNParams p;
     deconv_dgrad_params(d, p);
     p.A = dy; p.B = w; p.alpha = alpha_dev; p.out = dx; p.accumulate = accumulate;
@@ -1058,6 +1063,7 @@ int bg_deconv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, floa
                       void* stream) {
     int rc = check_deconv(d);
     if (rc) return rc;
+    BG_REQUIRE(x && dy && dw, "bg_deconv2d_wgrad: null tensor pointer");
     // dw[kh,kw,co,ci] = sum_{b,hi,wi} dy[b, hi*s+kh-pad, wi*s+kw-pad, co] * x[b,hi,wi,ci]
     TNParams p;
     memset(&p, 0, sizeof(p));
@@ -1091,6 +1097,7 @@ int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bi
             float* C, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     BG_REQUIRE(d != nullptr, "null BgGemmDesc");
     BG_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch >= 1, "BgGemmDesc: non-positive dimension");
+    BG_REQUIRE(A && B && C, "bg_gemm: null tensor pointer");
     const double flops = 2.0 * d->M * d->N * d->K * d->batch;
     Tag tag("gemm", d);
     if (!d->transA) {

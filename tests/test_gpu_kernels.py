@@ -579,3 +579,45 @@ def test_adam_tf_ema_step():
     assert rel_err(t2n(mc), m2) < 1e-7
     assert rel_err(t2n(vc), v2) < 1e-6
     assert rel_err(t2n(ec), 0.999 * ema + 0.001 * p2) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------
+# error behaviour of the C ABI: return codes + bg_last_error(), never a crash
+# ------------------------------------------------------------------------------------------
+def test_abi_rejects_bad_arguments_with_error_codes():
+    Fn, hip = _fn(), _hip()
+    L = hip.lib()
+    x = torch.zeros(2, 8, 8, 16, device="cuda")
+    w = torch.zeros(3, 3, 16, 32, device="cuda")
+    y = torch.zeros(2, 8, 8, 32, device="cuda")
+    good = hip.conv_desc(2, 8, 8, 16, 8, 8, 32, 3, 1, 1, hip.PAD_REFLECT)
+    assert L.bg_conv2d_fwd(good, hip.f32(x), hip.f32(w), None, None, hip.f32(y), 0, None, 0, hip.stream()) == 0
+    # null pointers, empty batch, zero channels, bad padding mode
+    assert L.bg_conv2d_fwd(good, None, hip.f32(w), None, None, hip.f32(y), 0, None, 0, hip.stream()) == 1
+    assert b"null tensor pointer" in L.bg_last_error()
+    for bad in (hip.conv_desc(0, 8, 8, 16, 8, 8, 32, 3, 1, 1, hip.PAD_REFLECT),
+                hip.conv_desc(2, 8, 8, 0, 8, 8, 32, 3, 1, 1, hip.PAD_REFLECT),
+                hip.conv_desc(2, 8, 8, 16, 8, 8, 32, 3, 1, 1, 7)):
+        assert L.bg_conv2d_fwd(bad, hip.f32(x), hip.f32(w), None, None, hip.f32(y), 0, None, 0, hip.stream()) != 0
+        with pytest.raises(RuntimeError):
+            hip.check(1)
+    # attention: unsupported shape is refused by the fused entry point (the Function falls back instead)
+    q = torch.zeros(1, 100, 8, device="cuda")
+    o = torch.zeros(1, 100, 8, device="cuda")
+    lse = torch.zeros(1, 100, device="cuda")
+    assert not L.bg_attention2_supported(100, 100, 8, 8)
+    assert L.bg_attention2_fwd(hip.f32(q), hip.f32(q), hip.f32(q), hip.f32(o), hip.f32(lse), 1, 100, 100, 8, 8,
+                               hip.stream()) != 0
+    assert b"unsupported shape" in L.bg_last_error()
+    # spectral-norm batch: more than 256 items per call is refused
+    assert L.bg_spectral_norm_batch_bwd(hip.f32(x), 300, None, None, hip.f32(x), 8 * 300, hip.stream()) != 0
+    # a workspace that is too small
+    d = hip.conv_desc(64, 4, 4, 1024, 4, 4, 1024, 3, 1, 1, hip.PAD_REFLECT)
+    need = L.bg_conv2d_wgrad_workspace_bytes(d)
+    assert need > 0
+    xx = torch.zeros(64, 4, 4, 1024, device="cuda")
+    dw = torch.zeros(3, 3, 1024, 1024, device="cuda")
+    small = torch.zeros(4, device="cuda")
+    rc = L.bg_conv2d_wgrad(d, hip.f32(xx), hip.f32(xx), hip.f32(dw), hip.f32(small), 16, hip.stream())
+    torch.cuda.synchronize()
+    assert rc == 0 or b"workspace" in L.bg_last_error()      # falls back to an unsplit launch or refuses; never overruns

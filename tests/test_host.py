@@ -97,6 +97,42 @@ def test_checkpoint_roundtrip_on_cpu(tmp_path):
     assert c.load(str(tmp_path / "nowhere")) == (False, 0)
 
 
+def test_abi_rejects_null_tensors_before_any_launch():
+    """Every int-returning entry point, given valid sizes / descriptors but NULL tensor pointers, must return
+    BG_ERR_ARG (1) from its argument validation - i.e. before it tries to launch anything (a launch attempt
+    would return BG_ERR_LAUNCH = 2 here, where there is no GPU; on a GPU it would fault)."""
+    import ctypes
+    L = hip.lib()
+    cd = hip.conv_desc(2, 8, 8, 16, 8, 8, 32, 3, 1, 1, 0)
+    dd = hip.conv_desc(2, 8, 8, 16, 16, 16, 32, 4, 2, 1, 1)
+    rd = hip.conv_desc(2, 8, 8, 16, 8, 8, 3, 3, 1, 1, 0)
+    td = hip.conv_desc(2, 8, 8, 3, 4, 4, 32, 3, 2, 1, 0)
+    gd = hip.BgGemmDesc(128, 128, 128, 0, 0, 128, 128, 128, 1, 0, 0, 0)
+    checked = 0
+    for name, (res, args) in hip.SIGNATURES.items():
+        if res is not ctypes.c_int or "supported" in name or name in ("bg_abi_version", "bg_get_gemm_compute",
+                                                                      "bg_prof_collect", "bg_prof_dump"):
+            continue
+        vals = []
+        for a in args:
+            if a is hip._CD:
+                vals.append(dd if "deconv" in name else rd if "rgb" in name else td if "thin" in name else cd)
+            elif a is hip._GD:
+                vals.append(gd)
+            elif a is ctypes.c_void_p or a is ctypes.c_char_p:
+                vals.append(None)
+            elif a in (ctypes.c_float, ctypes.c_double):
+                vals.append(1.0)
+            elif a is ctypes.c_size_t:
+                vals.append(1 << 20)
+            else:
+                vals.append(128)
+        rc = getattr(L, name)(*vals)
+        assert rc == 1, (name, rc, L.bg_last_error())
+        checked += 1
+    assert checked >= 50
+
+
 def test_out_of_scope_flags_rejected_at_build():
     for extra in (["--deep", "true"], ["--cls_embedding", "true"], ["--gan_type", "ra-dragan"], ["--g_final_layer", "true"],
                   ["--bn_type", "batch_renorm"], ["--d_cls_dense_layers", "true"]):
