@@ -210,6 +210,26 @@ def test_deconv_matches_tf_gradient_definition(k, s):
     assert rel_err(t2n(y), ref) < TOL
 
 
+@pytest.mark.parametrize("stride", [1, 2])
+def test_deconv_reproduces_tensorflow_unit_test_closed_forms(stride):
+    """The all-ones cases of TensorFlow's conv2d_transpose_test.py (testConv2DTransposeSingleStride: 12 / 18 / 27;
+    testConv2DTransposeSame: 3 / 6 / 12 by parity of the output index) through the HIP kernel - a published
+    known answer for the SAME transposed-conv alignment, including the asymmetric k3 s2 case (pad_lo 0)."""
+    Fn = _fn()
+    x = torch.ones(2, 6, 4, 3, device="cuda")
+    f = torch.ones(3, 3, 2, 3, device="cuda")
+    tot = max((6 - 1) * stride + 3 - stride * 6, 0)
+    y = t2n(Fn.Deconv2dFn.apply(x, f, None, stride, tot // 2, None))
+
+    def counts(n):
+        if stride == 1:
+            return np.array([3.0 if 0 < i < n - 1 else 2.0 for i in range(n)])
+        return np.array([2.0 if (i % 2 == 0 and 0 < i < n - 1) else 1.0 for i in range(n)])
+    expect = 3.0 * np.outer(counts(6 * stride), counts(4 * stride))
+    assert y.shape == (2, 6 * stride, 4 * stride, 2)
+    assert np.array_equal(y[0, :, :, 0], expect) and np.array_equal(y[1, :, :, 1], expect)
+
+
 def test_deconv_accumulate_into_epilogue():
     Fn = _fn()
     rng = np.random.default_rng(3)

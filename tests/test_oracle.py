@@ -5,6 +5,7 @@ algebraic invariants listed in SURVEY.md section 8(c)."""
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import kat
 from oracle import ref_ops as R
@@ -322,3 +323,58 @@ def test_adam_tf_form():
     v = 0.1 * np.array([0.25, 0.0625])
     exp = np.array([1.0, -2.0]) - lr_t * np.array([0.5, -0.25]) / (np.sqrt(v) + 1e-8)
     np.testing.assert_allclose(p["a"].numpy(), exp, rtol=1e-14)
+
+
+# ----------------------------------------------------------------------------------
+# known answers PUBLISHED by TensorFlow itself (documentation examples and the closed forms asserted by its
+# own unit tests), restated here because TensorFlow cannot be installed: they pin the two alignment
+# conventions the whole path rests on independently of this repository's own derivations
+# ----------------------------------------------------------------------------------
+def test_tf_pad_reflect_documentation_example():
+    """tf.pad docs: t = [[1,2,3],[4,5,6]], paddings [[1,1],[2,2]], mode REFLECT."""
+    from oracle import kat
+    t = np.array([[1, 2, 3], [4, 5, 6]], np.float64)
+    expect = np.array([[6, 5, 4, 5, 6, 5, 4],
+                       [3, 2, 1, 2, 3, 2, 1],
+                       [6, 5, 4, 5, 6, 5, 4],
+                       [3, 2, 1, 2, 3, 2, 1]], np.float64)
+    # kat.reflect_pad pads H and W by the same (lo, hi): pad by (2, 2) and crop the row axis back to (1, 1)
+    got = kat.reflect_pad(t[None, :, :, None], 2, 2)[0, 1:-1, :, 0]
+    assert np.array_equal(got, expect)
+    assert np.array_equal(F.pad(torch.tensor(t)[None, None], (2, 2, 1, 1), mode="reflect")[0, 0].numpy(), expect)
+
+
+def _tf_transpose_conv_counts(n_out, stride, k, single_stride):
+    """Closed forms asserted by TensorFlow's conv2d_transpose_test.py for all-ones inputs and filters."""
+    v = np.zeros(n_out)
+    for i in range(n_out):
+        if single_stride:              # testConv2DTransposeSingleStride: k 3, stride 1: 2 taps at the border, 3 inside
+            v[i] = 3 if 0 < i < n_out - 1 else 2
+        else:                          # testConv2DTransposeSame: k 3, stride 2: 2 taps at even interior rows, else 1
+            v[i] = 2 if (i % stride == 0 and 0 < i < n_out - 1) else 1
+    return v
+
+
+def test_tf_conv2d_transpose_unit_test_closed_forms():
+    """testConv2DTransposeSingleStride: x ones [2,6,4,3], f ones [3,3,2,3], strides 1, SAME -> 12 at the corners,
+    18 on the edges, 27 inside (target 4*3, +2*3, +5*3).  testConv2DTransposeSame: strides 2, output [2,12,8,2] ->
+    3 everywhere, +3 where exactly one of (h, w) is an even interior index, +9 where both are."""
+    from oracle import kat
+    x = np.ones((2, 6, 4, 3))
+    f = np.ones((3, 3, 2, 3))
+    for stride, single in ((1, True), (2, False)):
+        y = kat.conv2d_transpose_same(x, f, stride)
+        assert y.shape == (2, 6 * stride, 4 * stride, 2)
+        ch = _tf_transpose_conv_counts(6 * stride, stride, 3, single)
+        cw = _tf_transpose_conv_counts(4 * stride, stride, 3, single)
+        expect = 3.0 * np.outer(ch, cw)
+        assert np.array_equal(y[0, :, :, 0], expect) and np.array_equal(y[1, :, :, 1], expect)
+        if single:
+            assert (expect[0, 0], expect[0, 1], expect[1, 1]) == (12.0, 18.0, 27.0)
+        else:
+            assert (expect[1, 1], expect[2, 1], expect[2, 2]) == (3.0, 6.0, 12.0)
+        # the fast formulation used by the oracle model agrees on this case for the shapes the path uses
+        if (3, stride) == (3, 1):
+            w = torch.tensor(f)
+            yt = F.conv_transpose2d(torch.tensor(x).permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), stride=1, padding=1)
+            assert np.array_equal(yt.permute(0, 2, 3, 1).numpy(), y)
