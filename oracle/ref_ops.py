@@ -364,15 +364,36 @@ def resblock(vs, scope, x_init, channels, opt, use_bias=True):
     return x + x_init
 
 
+def upconv(vs, scope, x, channels, opt, use_bias=True):
+    """ops.py:200-218: --upsampling_method deconv3 / deconv4 (default) / deconv6 = transposed conv k, stride 2."""
+    m = opt.get("upsampling_method", "deconv4")
+    k = {"deconv3": 3, "deconv4": 4, "deconv6": 6}.get(m)
+    if k is None:
+        raise ValueError("Invalid upsampling method specified: " + str(m))
+    return deconv(vs, scope + "/deconv_0", x, channels, opt, kernel=k, stride=2, use_bias=use_bias)
+
+
+def g_conv(vs, scope, x, channels, opt, use_bias=True):
+    """ops.py:220-230: --g_conv deconv3 (default) / deconv4 (stride 1) / conv3 (reflect-padded conv)."""
+    m = opt.get("g_conv", "deconv3")
+    if m == "deconv3":
+        return deconv(vs, scope + "/deconv_0", x, channels, opt, kernel=3, stride=1, use_bias=use_bias)
+    if m == "deconv4":
+        return deconv(vs, scope + "/deconv_0", x, channels, opt, kernel=4, stride=1, use_bias=use_bias)
+    if m == "conv3":
+        return conv(vs, scope + "/conv_0", x, channels, opt, kernel=3, stride=1, pad=1, use_bias=use_bias)
+    raise ValueError("Invalid generator convolution type specified: " + str(m))
+
+
 def resblock_up_condition(vs, scope, x_init, z, channels, opt, use_bias=True, is_training=True):
-    """ops.py:250-266 with upconv = deconv k4 s2 (ops.py:203-204), g_conv = deconv k3 s1 (221-222)."""
+    """ops.py:250-266; defaults: upconv = deconv k4 s2 (ops.py:203-204), g_conv = deconv k3 s1 (221-222)."""
     x = condition_batch_norm(vs, scope + "/res1/batch_norm", x_init, z, opt, is_training)
     x = activation(vs, scope + "/res1/prelu", x, opt)
-    x = deconv(vs, scope + "/res1/deconv_0", x, channels, opt, kernel=4, stride=2, use_bias=use_bias)
+    x = upconv(vs, scope + "/res1", x, channels, opt, use_bias=use_bias)
     x = condition_batch_norm(vs, scope + "/res2/batch_norm", x, z, opt, is_training)
     x = activation(vs, scope + "/res2/prelu", x, opt)
-    x = deconv(vs, scope + "/res2/deconv_0", x, channels, opt, kernel=3, stride=1, use_bias=use_bias)
-    skip = deconv(vs, scope + "/skip/deconv_0", x_init, channels, opt, kernel=4, stride=2, use_bias=use_bias)
+    x = g_conv(vs, scope + "/res2", x, channels, opt, use_bias=use_bias)
+    skip = upconv(vs, scope + "/skip", x_init, channels, opt, use_bias=use_bias)
     return x + skip
 
 

@@ -198,7 +198,7 @@ def test_deconv2d_fwd_bwd(N, H, Cin, Cout, k, s):
     assert rel_err(t2n(bc.grad), bt.grad.numpy()) < TOL
 
 
-@pytest.mark.parametrize("k,s", [(4, 2), (3, 1)])
+@pytest.mark.parametrize("k,s", [(4, 2), (3, 1), (3, 2), (6, 2), (4, 1)])
 def test_deconv_matches_tf_gradient_definition(k, s):
     """KAT: tf.nn.conv2d_transpose(SAME) as the input-gradient of a SAME conv (no flip, low crop 1)."""
     Fn = _fn()
@@ -206,8 +206,19 @@ def test_deconv_matches_tf_gradient_definition(k, s):
     x = rng.standard_normal((2, 5, 5, 4))
     w = rng.standard_normal((k, k, 3, 4))
     ref = kat.conv2d_transpose_same(x, w, s)
-    y = Fn.Deconv2dFn.apply(cu(x), cu(w), None, s, 1, None)
+    pad_lo = max((5 - 1) * s + k - s * 5, 0) // 2                  # ops.py:128 'SAME': 1 for (4,2),(3,1); 0, 2, 1 for the rest
+    xc, wc = cu(x, True), cu(w, True)
+    y = Fn.Deconv2dFn.apply(xc, wc, None, s, pad_lo, None)
     assert rel_err(t2n(y), ref) < TOL
+    # gradients of the non-default (asymmetric) alignments too: adjoint identities against the KAT forward
+    g = rng.standard_normal(ref.shape)
+    y.backward(cu(g))
+    eps_x, eps_w = rng.standard_normal(x.shape), rng.standard_normal(w.shape)
+    lhs_x = float((t2n(xc.grad) * eps_x).sum())
+    rhs_x = float((kat.conv2d_transpose_same(eps_x, w, s) * g).sum())
+    lhs_w = float((t2n(wc.grad) * eps_w).sum())
+    rhs_w = float((kat.conv2d_transpose_same(x, eps_w, s) * g).sum())
+    assert abs(lhs_x - rhs_x) < 1e-4 * max(abs(rhs_x), 1.0) and abs(lhs_w - rhs_w) < 1e-4 * max(abs(rhs_w), 1.0)
 
 
 @pytest.mark.parametrize("stride", [1, 2])

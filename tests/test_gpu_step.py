@@ -322,10 +322,16 @@ def test_sample_with_ema_weights():
     (dict(activation="lrelu"), dict(activation="lrelu")),
     (dict(conv_padding="zero"), dict(conv_padding="zero")),
     (dict(bn_in_d=True), dict(bn_in_d="true")),
+    (dict(upsampling_method="deconv3"), dict(upsampling_method="deconv3")),
+    (dict(upsampling_method="deconv6"), dict(upsampling_method="deconv6")),
+    (dict(g_conv="deconv4"), dict(g_conv="deconv4")),
+    (dict(g_conv="conv3"), dict(g_conv="conv3")),
 ])
 def test_step_parity_non_default_flags(okw, hkw):
     """--activation relu / lrelu (BigGAN.py:71-83), --conv_padding zero (TF SAME,
-    ops.py:79-80), --bn_in_d (ops.py:191,296; D then runs once per real / fake batch as in the reference)."""
+    ops.py:79-80), --bn_in_d (ops.py:191,296; D then runs once per real / fake batch as in the reference),
+    --upsampling_method deconv3 / deconv6 and --g_conv deconv4 / conv3 (ops.py:200-230; the asymmetric TF 'SAME'
+    alignments of k3 s2 and k4 s1 transposed convolutions)."""
     tr = oracle_trainer(64, 8, 64, 4, **okw)
     gan = hip_model_like(tr, **hkw)
     batch = RM.synthetic_batch(tr.cfg, 13, 4)
