@@ -400,6 +400,71 @@ __global__ __launch_bounds__(EW_BLOCK) void maxpool2_fwd_kernel(const float* __r
     }
 }
 
+// 2x2 box reduce: y[n,ho,wo,c] = scale * (x[2ho,2wo] + x[2ho,2wo+1] + x[2ho+1,2wo] + x[2ho+1,2wo+1])
+//   avg_pooling forward (scale 1/4, ops.py:512-514) and the backward of up_sample (scale 1)
+template <int VEC>
+__global__ __launch_bounds__(EW_BLOCK) void box2_down_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              int N, int H, int W, int C, float scale) {
+    const int CV = C / VEC, Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)N * Ho * Wo * CV;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int cv = (int)(i % CV);
+        int64_t t = i / CV;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const float* p = x + (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + cv * VEC;
+        float a[VEC], b[VEC], c_[VEC], d[VEC];
+        loadv<VEC>(p, a);
+        loadv<VEC>(p + C, b);
+        loadv<VEC>(p + (int64_t)W * C, c_);
+        loadv<VEC>(p + (int64_t)W * C + C, d);
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = scale * ((a[j] + b[j]) + (c_[j] + d[j]));
+        if constexpr (VEC == 4)
+            stg4(y + i * 4, make_float4(o[0], o[1], o[2], o[VEC - 1]));
+        else
+            y[i] = o[0];
+    }
+}
+
+// 2x2 replicate: y[n,2hi+a,2wi+b,c] = scale * x[n,hi,wi,c]
+//   up_sample forward (tf.image.resize_nearest_neighbor x2, scale 1, ops.py:516-519) and avg_pooling backward (1/4)
+template <int VEC>
+__global__ __launch_bounds__(EW_BLOCK) void box2_up_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                            int H, int W, int C, float scale) {
+    const int CV = C / VEC;
+    const int64_t total = (int64_t)N * H * W * CV;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int cv = (int)(i % CV);
+        int64_t t = i / CV;
+        const int wi = (int)(t % W);
+        t /= W;
+        const int hi = (int)(t % H);
+        const int n = (int)(t / H);
+        float a[VEC];
+        loadv<VEC>(x + i * VEC, a);
+        float* q = y + (((int64_t)n * 2 * H + 2 * hi) * 2 * W + 2 * wi) * C + cv * VEC;
+        const int64_t row = (int64_t)2 * W * C;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) a[j] *= scale;
+        if constexpr (VEC == 4) {
+            const float4 v = make_float4(a[0], a[1], a[2], a[VEC - 1]);
+            stg4(q, v);
+            stg4(q + C, v);
+            stg4(q + row, v);
+            stg4(q + row + C, v);
+        } else {
+            q[0] = a[0];
+            q[C] = a[0];
+            q[row] = a[0];
+            q[row + C] = a[0];
+        }
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(EW_BLOCK) void maxpool2_bwd_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ dy, float* __restrict__ dx,
@@ -1039,6 +1104,32 @@ int bg_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, in
     else
         hipLaunchKernelGGL((maxpool2_bwd_kernel<1>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), x, dy,
                            dx, N, H, W, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_box2_down(const float* x, float* y, int N, int H, int W, int C, float scale, void* stream) {
+    BG_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, "bg_box2_down: bad argument");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((box2_down_kernel<4>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK), 0, as_stream(stream), x, y,
+                           N, H, W, C, scale);
+    else
+        hipLaunchKernelGGL((box2_down_kernel<1>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), x, y, N,
+                           H, W, C, scale);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_box2_up(const float* x, float* y, int N, int H, int W, int C, float scale, void* stream) {
+    BG_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "bg_box2_up: bad argument");
+    const int64_t total = (int64_t)N * H * W * C;
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((box2_up_kernel<4>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK), 0, as_stream(stream), x, y, N,
+                           H, W, C, scale);
+    else
+        hipLaunchKernelGGL((box2_up_kernel<1>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), x, y, N, H,
+                           W, C, scale);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -590,6 +590,48 @@ class MaxPool2Fn(Function):
         return dx
 
 
+class AvgPool2Fn(Function):
+    """tf.layers.average_pooling2d(pool 2, strides 2) on even H, W (ops.py:512-514)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, H, W_, C = x.shape
+        y = torch.empty((N, H // 2, W_ // 2, C), dtype=torch.float32, device=x.device)
+        check(lib().bg_box2_down(f32(x), f32(y), N, H, W_, C, 0.25, stream()))
+        ctx.shape = (N, H, W_, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        N, H, W_, C = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        check(lib().bg_box2_up(f32(dy), f32(dx), N, H // 2, W_ // 2, C, 0.25, stream()))
+        return dx
+
+
+class UpSample2Fn(Function):
+    """tf.image.resize_nearest_neighbor to twice the size (ops.py:516-519)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, H, W_, C = x.shape
+        y = torch.empty((N, 2 * H, 2 * W_, C), dtype=torch.float32, device=x.device)
+        check(lib().bg_box2_up(f32(x), f32(y), N, H, W_, C, 1.0, stream()))
+        ctx.shape = (N, H, W_, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        N, H, W_, C = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        check(lib().bg_box2_down(f32(dy), f32(dx), N, 2 * H, 2 * W_, C, 1.0, stream()))
+        return dx
+
+
 class SumPoolFn(Function):
     @staticmethod
     def forward(ctx, x):

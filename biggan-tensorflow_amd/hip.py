@@ -86,6 +86,8 @@ SIGNATURES = {
     "bg_prelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "bg_maxpool2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "bg_maxpool2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "bg_box2_down": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "bg_box2_up": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "bg_softmax_fwd": (c_int, [_P, _P, c_int64, c_int, _P]),
     "bg_softmax_bwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "bg_sum_pool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),

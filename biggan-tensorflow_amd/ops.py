@@ -250,7 +250,14 @@ def upconv(x, channels, opt, use_bias=True, _accumulate_into=None):
         return deconv(x, channels, kernel=4, stride=2, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into)
     elif m == 'deconv6':
         return deconv(x, channels, kernel=6, stride=2, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into)
-    elif m in ('subpixel2', 'subpixel3', 'resize_conv', 'nn'):
+    elif m == 'resize_conv':
+        x = up_sample(x, 2)
+        y = conv(x, channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
+        return y if _accumulate_into is None else _add(y, _accumulate_into)
+    elif m == 'nn':
+        y = up_sample(x, 2)
+        return y if _accumulate_into is None else _add(y, _accumulate_into)
+    elif m in ('subpixel2', 'subpixel3'):
         raise NotImplementedError("upsampling_method %s is outside the default hot path" % m)
     else:
         raise ValueError("Invalid upsampling method specified: " + str(m))
@@ -312,8 +319,18 @@ def downconv(x, channels, opt, use_bias=True, method=None):
         method = opt["downsampling_method"]
     if method == 'strided_conv3':
         return conv(x, channels, kernel=3, stride=2, pad=1, use_bias=use_bias, opt=opt)
-    elif method in ('resize_conv1', 'resize_conv3', 'resize_conv35', 'pool_only', 'max_pool_only'):
-        raise NotImplementedError("downsampling_method %s is outside the default hot path" % method)
+    elif method == 'resize_conv1':
+        x = conv(x, channels, kernel=1, stride=1, pad=0, use_bias=use_bias, opt=opt)
+        return avg_pooling(x)
+    elif method == 'resize_conv3':
+        x = conv(x, channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
+        return avg_pooling(x)
+    elif method == 'pool_only':
+        return avg_pooling(x)
+    elif method == 'max_pool_only':
+        return max_pooling(x)
+    elif method == 'resize_conv35':
+        raise NotImplementedError("downsampling_method %s (mixed kernels) is outside the default hot path" % method)
     else:
         raise ValueError("Invalid downsampling method specified: " + str(method))
 
@@ -408,11 +425,21 @@ def max_pooling(x):
 
 
 def avg_pooling(x):
-    raise NotImplementedError("avg_pooling (ops.py:512) is outside the default hot path")
+    """ops.py:512-514 (2x2, stride 2, 'SAME'; even H and W)."""
+    if x.shape[1] % 2 or x.shape[2] % 2:
+        raise NotImplementedError("avg_pooling on odd spatial sizes")
+    if _is_meta(x):
+        return _meta((x.shape[0], x.shape[1] // 2, x.shape[2] // 2, x.shape[3]))
+    return Fn.AvgPool2Fn.apply(x)
 
 
 def up_sample(x, scale_factor=2):
-    raise NotImplementedError("up_sample (ops.py:516) is outside the default hot path")
+    """ops.py:516-519: tf.image.resize_nearest_neighbor to scale_factor times the size."""
+    if scale_factor != 2:
+        raise NotImplementedError("up_sample scale_factor != 2")
+    if _is_meta(x):
+        return _meta((x.shape[0], x.shape[1] * 2, x.shape[2] * 2, x.shape[3]))
+    return Fn.UpSample2Fn.apply(x)
 
 
 ##################################################################################

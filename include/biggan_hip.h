@@ -219,6 +219,12 @@ int bg_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx,
 /* tf.layers.max_pooling2d(2,2,'SAME') on even H,W (ops.py:508-510); bwd routes to the first max */
 int bg_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int bg_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* 2x2 stride-2 box kernels (x is [N,H,W,C] for both): bg_box2_down: y[N,H/2,W/2,C] = scale * sum of each 2x2
+ * block (avg_pooling forward with scale 1/4, ops.py:512-514; up_sample backward with scale 1);
+ * bg_box2_up: y[N,2H,2W,C] = scale * x replicated 2x2 (up_sample = resize_nearest_neighbor x2 forward with
+ * scale 1, ops.py:516-519; avg_pooling backward with scale 1/4). */
+int bg_box2_down(const float* x, float* y, int N, int H, int W, int C, float scale, void* stream);
+int bg_box2_up(const float* x, float* y, int N, int H, int W, int C, float scale, void* stream);
 
 /* tf.nn.softmax over the last axis (ops.py:483): rows x cols, in place allowed; bwd: ds = p*(dp - sum(dp*p)) */
 int bg_softmax_fwd(const float* s, float* p, int64_t rows, int cols, void* stream);

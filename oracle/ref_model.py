@@ -34,6 +34,7 @@ class Config:
         self.activation = "prelu"             # main.py:63
         self.upsampling_method = "deconv4"    # main.py:52
         self.g_conv = "deconv3"               # main.py:54
+        self.downsampling_method = "strided_conv3"   # main.py:53
         self.bn_in_d = False                  # main.py:40
         self.g_grow_factor = 2.0
         self.d_grow_factor = 2.0
@@ -106,7 +107,8 @@ class Config:
 def _conv_opt(cfg, training, generator):
     opt = {"sn": cfg.sn, "padding_type": cfg.conv_padding, "bn_momentum": cfg.bn_momentum,
            "self_attention_bias": cfg.bias_in_sa, "regularizer": None, "act": cfg.activation,
-           "bn_in_d": cfg.bn_in_d, "upsampling_method": cfg.upsampling_method, "g_conv": cfg.g_conv}
+           "bn_in_d": cfg.bn_in_d, "upsampling_method": cfg.upsampling_method, "g_conv": cfg.g_conv,
+           "downsampling_method": cfg.downsampling_method}
     if generator and training and cfg.g_regularization != "none":           # BigGAN.py:257-274
         opt["regularizer"] = {"scale": cfg.g_regularization_factor, "type": cfg.g_regularization}
     return opt

@@ -293,6 +293,14 @@ def max_pooling(x):                               # ops.py:508-510 (even H, W: 2
     return _nhwc(F.max_pool2d(_nchw(x), 2, 2))
 
 
+def avg_pooling(x):                               # ops.py:512-514 (even H, W)
+    return _nhwc(F.avg_pool2d(_nchw(x), 2, 2))
+
+
+def up_sample(x):                                 # ops.py:516-519: nearest neighbour x2
+    return x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+
+
 def global_sum_pooling(x):                        # ops.py:503-506
     return x.sum(dim=(1, 2))
 
@@ -367,6 +375,8 @@ def resblock(vs, scope, x_init, channels, opt, use_bias=True):
 def upconv(vs, scope, x, channels, opt, use_bias=True):
     """ops.py:200-218: --upsampling_method deconv3 / deconv4 (default) / deconv6 = transposed conv k, stride 2."""
     m = opt.get("upsampling_method", "deconv4")
+    if m == "resize_conv":
+        return conv(vs, scope + "/conv_0", up_sample(x), channels, opt, kernel=3, stride=1, pad=1, use_bias=use_bias)
     k = {"deconv3": 3, "deconv4": 4, "deconv6": 6}.get(m)
     if k is None:
         raise ValueError("Invalid upsampling method specified: " + str(m))
@@ -397,18 +407,33 @@ def resblock_up_condition(vs, scope, x_init, z, channels, opt, use_bias=True, is
     return x + skip
 
 
+def downconv(vs, scope, x, channels, opt, use_bias=True, method=None):
+    """ops.py:269-291: strided_conv3 (default), resize_conv1 / resize_conv3 = conv k1 / k3 stride 1 + avg pool."""
+    m = method or opt.get("downsampling_method", "strided_conv3")
+    if m == "strided_conv3":
+        return conv(vs, scope + "/conv_0", x, channels, opt, kernel=3, stride=2, pad=1, use_bias=use_bias)
+    if m == "resize_conv1":
+        return avg_pooling(conv(vs, scope + "/conv_0", x, channels, opt, kernel=1, stride=1, pad=0, use_bias=use_bias))
+    if m == "resize_conv3":
+        return avg_pooling(conv(vs, scope + "/conv_0", x, channels, opt, kernel=3, stride=1, pad=1, use_bias=use_bias))
+    raise ValueError("Invalid downsampling method specified: " + str(m))
+
+
 def resblock_down(vs, scope, x_init, channels, opt, use_bias=True):
-    """ops.py:293-313 with downconv = conv k3 s2 pad 1 (ops.py:273-274)."""
+    """ops.py:293-313; the residual path uses resize_conv3 whenever the method is not strided_conv3 (299-302)."""
     x = x_init
     if opt.get("bn_in_d"):
         x = batch_norm(vs, scope + "/res1/batch_norm", x, opt, True)
     x = activation(vs, scope + "/res1/prelu", x, opt)
-    x = conv(vs, scope + "/res1/conv_0", x, channels, opt, kernel=3, stride=2, pad=1, use_bias=use_bias)
+    res_method = opt.get("downsampling_method", "strided_conv3")
+    if res_method != "strided_conv3":
+        res_method = "resize_conv3"
+    x = downconv(vs, scope + "/res1", x, channels, opt, use_bias=use_bias, method=res_method)
     if opt.get("bn_in_d"):
         x = batch_norm(vs, scope + "/res2/batch_norm", x, opt, True)
     x = activation(vs, scope + "/res2/prelu", x, opt)
     x = conv(vs, scope + "/res2/conv_0", x, channels, opt, kernel=3, stride=1, pad=1, use_bias=use_bias)
-    skip = conv(vs, scope + "/skip/conv_0", x_init, channels, opt, kernel=3, stride=2, pad=1, use_bias=use_bias)
+    skip = downconv(vs, scope + "/skip", x_init, channels, opt, use_bias=use_bias)
     return x + skip
 
 

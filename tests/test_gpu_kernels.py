@@ -462,6 +462,31 @@ def test_prelu(shape):
     assert rel_err(t2n(ac.grad), at.grad.numpy()) < 5e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8, 16), (3, 4, 6, 5), (1, 2, 2, 64)])
+def test_avg_pool_and_nearest_upsample(shape):
+    """ops.py:512-519: avg_pooling (2x2, stride 2) and up_sample (nearest x2), forward and backward."""
+    Fn = _fn()
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape)
+    xt = torch.tensor(x, requires_grad=True)
+    yr = F.avg_pool2d(xt.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    g = rng.standard_normal(tuple(yr.shape))
+    yr.backward(torch.tensor(g))
+    xc = cu(x, True)
+    y = Fn.AvgPool2Fn.apply(xc)
+    y.backward(cu(g))
+    assert rel_err(t2n(y), yr.detach().numpy()) < TOL and rel_err(t2n(xc.grad), xt.grad.numpy()) < TOL
+    xt2 = torch.tensor(x, requires_grad=True)
+    ur = xt2.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    g2 = rng.standard_normal(tuple(ur.shape))
+    ur.backward(torch.tensor(g2))
+    xc2 = cu(x, True)
+    u = Fn.UpSample2Fn.apply(xc2)
+    u.backward(cu(g2))
+    assert np.array_equal(t2n(u), ur.detach().numpy().astype(np.float32))
+    assert rel_err(t2n(xc2.grad), xt2.grad.numpy()) < TOL
+
+
 def test_pooling_tanh_scaleadd():
     Fn = _fn()
     rng = np.random.default_rng(9)

@@ -25,19 +25,33 @@ def _loss_close(a, b):
     return abs(a - b) / max(abs(b), 1e-6) <= LOSS_TOL
 
 
+def _vanishing(name, grads):
+    """A bias whose gradient is exactly zero in exact arithmetic: the key-side bias of the attention logits
+    (softmax is invariant to a per-query constant), or a per-channel constant that a later batch norm removes
+    again (e.g. the attention biases in front of reflect-padded convolutions with --upsampling_method resize_conv:
+    REFLECT padding maps constants to constants).  The float64 reference gives ~1e-16 of the sibling kernel's
+    gradient there; the fp32 value is cancellation noise."""
+    if not name.endswith("/bias"):
+        return False
+    kern = grads.get(name.replace("/bias", "/kernel"))
+    if kern is None:
+        return False
+    return float(np.linalg.norm(grads[name].numpy())) < 1e-9 * float(np.linalg.norm(kern.numpy()))
+
+
 def _scale_ref(name, grads):
-    """The key-side bias of the attention logits (f_conv/bias) has an exactly-zero gradient in exact
-    arithmetic (softmax is invariant to a per-query constant); its fp32 value is cancellation noise of
-    the same layer's kernel gradient, so that norm is the error scale."""
-    if name.endswith("self_attention/f_conv/bias"):
+    """Error scale of a vanishing-gradient bias: the same layer's kernel-gradient norm."""
+    if _vanishing(name, grads):
         return float(np.linalg.norm(grads[name.replace("/bias", "/kernel")].numpy()))
     return 0.0
 
 
-def _noise_driven(name):
+def _noise_driven(name, grads=None):
     """Adam with beta1 = 0 turns ANY non-zero gradient into a +-lr-sized update, so the post-step value
     of a parameter whose exact gradient is zero is rounding noise on every platform (TensorFlow too)."""
-    return name.endswith("self_attention/f_conv/bias")
+    if name.endswith("self_attention/f_conv/bias"):
+        return True
+    return grads is not None and name in grads and _vanishing(name, grads)
 
 
 def _state_err(hip_v, ref_v, g_ref=None):
@@ -154,7 +168,7 @@ def _run_parity(tr, gan, batch, check_state=True):
     after = tr.vs.export()
     hip1 = gan.store.export_arrays()
     for k in after:
-        if _noise_driven(k):
+        if _noise_driven(k, rd["grads"]):
             continue
         if k.endswith("/u") and after[k].size == 1:
             pass
@@ -171,7 +185,7 @@ def _run_parity(tr, gan, batch, check_state=True):
     after2 = tr.vs.export()
     hip2 = gan.store.export_arrays()
     for k in after2:
-        if _noise_driven(k):
+        if _noise_driven(k, ro["grads"]):
             continue
         if k.endswith("/u") and after2[k].size == 1:
             pass                         # a 1-element u is +-1 up to an ulp after its first update
@@ -183,7 +197,7 @@ def _run_parity(tr, gan, batch, check_state=True):
         e = _state_err(hip2[k], after2[k], None if gk is None else gk.numpy()) if np.linalg.norm(after2[k]) > 0 else 0.0
         assert e < STATE_TOL, ("g-step state", k, e)
     for k, s_ in tr.ema.items():
-        if _noise_driven(k):
+        if _noise_driven(k, ro["grads"]):
             continue
         gk = ro["grads"].get(k)
         e = _state_err(t2n(gan.g_arena.view(gan.g_arena.ema, k)), s_.numpy(), None if gk is None else gk.numpy())
@@ -326,6 +340,9 @@ def test_sample_with_ema_weights():
     (dict(upsampling_method="deconv6"), dict(upsampling_method="deconv6")),
     (dict(g_conv="deconv4"), dict(g_conv="deconv4")),
     (dict(g_conv="conv3"), dict(g_conv="conv3")),
+    (dict(upsampling_method="resize_conv"), dict(upsampling_method="resize_conv")),
+    (dict(downsampling_method="resize_conv1"), dict(downsampling_method="resize_conv1")),
+    (dict(downsampling_method="resize_conv3"), dict(downsampling_method="resize_conv3")),
 ])
 def test_step_parity_non_default_flags(okw, hkw):
     """--activation relu / lrelu (BigGAN.py:71-83), --conv_padding zero (TF SAME,
