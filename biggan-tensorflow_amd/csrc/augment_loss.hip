@@ -354,6 +354,21 @@ __global__ __launch_bounds__(AL_BLOCK) void ortho_lowrank_finish_kernel(float* _
     }
 }
 
+// plain 'ortho' regulariser (utils.py:199-200): reg = A - I, loss = scale * l2_loss(reg), dA = scale * reg
+__global__ __launch_bounds__(AL_BLOCK) void ortho_identity_kernel(const float* __restrict__ A, float scale,
+                                                                   float* loss_accum, float* __restrict__ dA, int c) {
+    __shared__ float sh[4];
+    const int64_t n = (int64_t)c * c;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * AL_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * AL_BLOCK) {
+        const float r = A[i] - ((i / c) == (i % c) ? 1.f : 0.f);
+        acc += r * r;
+        if (dA) dA[i] = scale * r;
+    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(loss_accum, 0.5f * scale * acc);
+}
+
 }  // namespace bg
 
 using namespace bg;
@@ -486,6 +501,16 @@ int bg_ortho_lowrank_finish(float* dW, const float* P, const float* s, const flo
 int bg_ortho_cosine_fwd_bwd(const float* A, float scale, float* loss_accum, float* dA, int c, void* stream) {
     BG_REQUIRE(A && loss_accum && c > 0, "bg_ortho_cosine_fwd_bwd: bad argument");
     hipLaunchKernelGGL(ortho_cosine_kernel, dim3(c), dim3(AL_BLOCK), 0, as_stream(stream), A, scale, loss_accum, dA, c);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_ortho_identity_fwd_bwd(const float* A, float scale, float* loss_accum, float* dA, int c, void* stream) {
+    BG_REQUIRE(A && loss_accum && c > 0, "bg_ortho_identity_fwd_bwd: bad argument");
+    int64_t blocks = ((int64_t)c * c + AL_BLOCK - 1) / AL_BLOCK;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(ortho_identity_kernel, dim3((unsigned)blocks), dim3(AL_BLOCK), 0, as_stream(stream), A, scale,
+                       loss_accum, dA, c);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

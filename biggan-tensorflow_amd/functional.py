@@ -862,13 +862,13 @@ class OrthoCosineRegFn(Function):
     The weight gradient dW = W (dA + dA^T) is produced in backward."""
 
     @staticmethod
-    def forward(ctx, w, scale):
+    def forward(ctx, w, scale, kind="ortho_cosine"):
         w = _c(w)
         c = w.shape[-1]
         rows = w.numel() // c
         W2 = w.view(rows, c)
         dev = w.device
-        ctx.lowrank = 2 * rows <= c
+        ctx.lowrank = 2 * rows <= c and kind == "ortho_cosine"
         if ctx.lowrank:
             # wide kernel: O(rows^2 c) form, the c x c Gram matrix is never materialised
             L = lib()
@@ -896,7 +896,10 @@ class OrthoCosineRegFn(Function):
         gemm(W2, W2, A, c, c, rows, c, c, c, transA=True)               # A = W^T W
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
         dA = torch.empty((c, c), dtype=torch.float32, device=dev)
-        check(lib().bg_ortho_cosine_fwd_bwd(f32(A), float(scale), f32(loss), f32(dA), c, stream()))
+        if kind == "ortho":                                              # utils.py:199-200: reg = A - I
+            check(lib().bg_ortho_identity_fwd_bwd(f32(A), float(scale), f32(loss), f32(dA), c, stream()))
+        else:
+            check(lib().bg_ortho_cosine_fwd_bwd(f32(A), float(scale), f32(loss), f32(dA), c, stream()))
         ctx.w, ctx.dA = w, dA
         return loss
 
@@ -910,7 +913,7 @@ class OrthoCosineRegFn(Function):
                 check(lib().bg_scale_dev(f32(dWs), f32(g), f32(out), dWs.numel(), stream()))
             dw = param_grad(w, ctx.needs_input_grad[0], prod_lr)
             ctx.w = ctx.dW = None
-            return dw, None
+            return dw, None, None
         w, dA = ctx.w, ctx.dA
         c = w.shape[-1]
         rows = w.numel() // c
@@ -922,4 +925,29 @@ class OrthoCosineRegFn(Function):
             gemm(W2, dA, o2, rows, c, c, c, c, c, transB=True, alpha_dev=g, accumulate=True)    # + W dA^T
         dw = param_grad(w, ctx.needs_input_grad[0], prod)
         ctx.w = ctx.dA = None
+        return dw, None, None
+
+
+class L2RegFn(Function):
+    """tf.contrib.layers.l2_regularizer(scale)(w) = scale * sum(w^2) / 2 (BigGAN.py:268-270)."""
+
+    @staticmethod
+    def forward(ctx, w, scale):
+        w = _c(w)
+        loss = torch.zeros(1, dtype=torch.float32, device=w.device)
+        check(lib().bg_dot(f32(w), f32(w), f32(loss), w.numel(), stream()))
+        axpby(loss, 0.0, loss, 0.5 * float(scale))
+        ctx.w, ctx.scale = w, float(scale)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        w, scale = ctx.w, ctx.scale
+
+        def prod(out):
+            check(lib().bg_scale_dev(f32(w), f32(g), f32(out), w.numel(), stream()))
+            axpby(out, 0.0, out, scale)
+        dw = param_grad(w, ctx.needs_input_grad[0], prod)
+        ctx.w = None
         return dw, None

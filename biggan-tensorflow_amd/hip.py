@@ -108,6 +108,7 @@ SIGNATURES = {
     "bg_hinge_g_grad": (c_int, [_P, c_double, c_float, _P, _P, c_int, _P]),
     "bg_sigmoid_ce": (c_int, [_P, _P, _P, c_float, _P, _P, c_int, c_int, _P]),
     "bg_ortho_cosine_fwd_bwd": (c_int, [_P, c_float, _P, _P, c_int, _P]),
+    "bg_ortho_identity_fwd_bwd": (c_int, [_P, c_float, _P, _P, c_int, _P]),
     "bg_gemv_rows": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "bg_ortho_lowrank_cols": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P]),
     "bg_ortho_lowrank_finish": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),

@@ -22,7 +22,7 @@ from . import hip
 from .ops import (fully_connected, resblock_up_condition, resblock_down, resblock, self_attention_2, conv, bn,
                   prelu, relu, lrelu, tanh, global_sum_pooling, discriminator_loss, generator_loss)
 from .DiffAugment import DiffAugment, draw as draw_augment
-from .utils import orthogonal_regularizer, orthogonal_regularizer_fc, round_up, cls_loss_fn
+from .utils import orthogonal_regularizer, orthogonal_regularizer_fc, l2_regularizer, round_up, cls_loss_fn
 
 
 class GANBase(object):
@@ -231,7 +231,8 @@ class BigGAN(GANBase):
                 opt["conv"]["regularizer"] = orthogonal_regularizer(self.g_regularization_factor, type=m)
                 opt["fc_regularizer"] = orthogonal_regularizer_fc(self.g_regularization_factor, type=m)
             elif m == 'l2':
-                raise NotImplementedError("--g_regularization l2 is outside the default hot path")
+                opt["conv"]["regularizer"] = l2_regularizer(self.g_regularization_factor)
+                opt["fc_regularizer"] = l2_regularizer(self.g_regularization_factor)
             else:
                 raise ValueError("Unknown regularization method: " + str(m))
         else:

@@ -35,15 +35,21 @@ def parse_int_list(str):
 ##################################################################################
 def orthogonal_regularizer(scale, type='ortho'):
     """utils.py:185-211.  Returns a callable w[k,k,a,c] -> scalar loss tensor (device)."""
-    if type == 'ortho':
-        raise NotImplementedError("g_regularization 'ortho' is outside the default hot path (use ortho_cosine or none)")
-    if type != 'ortho_cosine':
+    if type not in ('ortho', 'ortho_cosine'):
         raise ValueError("Unknown regularization method.")
 
     def ortho_reg(w):
         from . import functional as Fn
-        return Fn.OrthoCosineRegFn.apply(w, scale)
+        return Fn.OrthoCosineRegFn.apply(w, scale, type)
     return ortho_reg
+
+
+def l2_regularizer(scale):
+    """tf.contrib.layers.l2_regularizer(scale) (BigGAN.py:268-270)."""
+    def l2_reg(w):
+        from . import functional as Fn
+        return Fn.L2RegFn.apply(w, scale)
+    return l2_reg
 
 
 def orthogonal_regularizer_fc(scale, type='ortho'):

@@ -285,6 +285,8 @@ int bg_sigmoid_ce(const float* logits, const float* truth, const float* weights,
  *   fwd: loss_accum[0] += scale/2 * sum R^2 ; bwd: dA (so that dW = W (dA + dA^T), via bg_gemm).
  * ------------------------------------------------------------------------------------------ */
 int bg_ortho_cosine_fwd_bwd(const float* A, float scale, float* loss_accum, float* dA, int c, void* stream);
+/* type 'ortho' (utils.py:199-200): loss_accum += scale/2 * sum (A - I)^2, dA = scale * (A - I). */
+int bg_ortho_identity_fwd_bwd(const float* A, float scale, float* loss_accum, float* dA, int c, void* stream);
 /* Low-rank form of the same function for wide kernels W[rows, c] with rows < c (first/dense2 is
  * [184, 16*16*ch]): with G = W W^T, s = W 1, P = G W (bg_gemm) the c x c Gram matrix is never formed.
  *   cols:   alpha_beta[0:c] = alpha, [c:2c] = beta, Wb = W diag(beta), loss_accum[0] += loss

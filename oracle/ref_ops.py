@@ -185,7 +185,9 @@ def _maybe_regularize(vs, opt, scope, w, kind):
         return
     if any(n == scope for n, _ in vs.reg_losses):
         return                       # reuse=True instantiation: variable (and its loss) already exist
-    if reg["type"] == "ortho_cosine" and w.shape[-1] > 256:
+    if reg["type"] == "l2":          # tf.contrib.layers.l2_regularizer: scale * sum(w^2) / 2 (BigGAN.py:268-270)
+        vs.reg_losses.append((scope, reg["scale"] * 0.5 * (w * w).sum()))
+    elif reg["type"] == "ortho_cosine" and w.shape[-1] > 256:
         # literal form is O(c^3) (8.8 TFLOP for first/dense2 at ch=64); the closed form is the same
         # function (tests/test_oracle.py::test_ortho_cosine_closed_form)
         vs.reg_losses.append((scope, ortho_cosine_closed_form(w, reg["scale"])))

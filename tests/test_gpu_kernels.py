@@ -618,6 +618,22 @@ def test_ortho_cosine_regulariser(shape):
     assert rel_err(t2n(wc.grad), wt.grad.numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("kind,shape", [("ortho", (3, 3, 8, 16)), ("ortho", (96, 184)), ("l2", (4, 4, 32, 8))])
+def test_ortho_identity_and_l2_regularisers(kind, shape):
+    """--g_regularization ortho (utils.py:199-200: l2_loss(W^T W - I)) and l2 (BigGAN.py:268-270)."""
+    Fn = _fn()
+    rng = np.random.default_rng(len(shape) + shape[-1])
+    w = rng.standard_normal(shape) * 0.1
+    wt = torch.tensor(w, requires_grad=True)
+    ref = R.ortho_reg_loss(wt, 1e-2, "ortho") if kind == "ortho" else 1e-2 * 0.5 * (wt * wt).sum()
+    ref.backward()
+    wc = cu(w, True)
+    loss = Fn.OrthoCosineRegFn.apply(wc, 1e-2, "ortho") if kind == "ortho" else Fn.L2RegFn.apply(wc, 1e-2)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert rel_err(t2n(wc.grad), wt.grad.numpy()) < 5e-5
+
+
 def test_adam_tf_ema_step():
     hip = _hip()
     rng = np.random.default_rng(17)

@@ -343,6 +343,8 @@ def test_sample_with_ema_weights():
     (dict(upsampling_method="resize_conv"), dict(upsampling_method="resize_conv")),
     (dict(downsampling_method="resize_conv1"), dict(downsampling_method="resize_conv1")),
     (dict(downsampling_method="resize_conv3"), dict(downsampling_method="resize_conv3")),
+    (dict(g_regularization="ortho"), dict()),
+    (dict(g_regularization="l2"), dict()),
 ])
 def test_step_parity_non_default_flags(okw, hkw):
     """--activation relu / lrelu (BigGAN.py:71-83), --conv_padding zero (TF SAME,
