@@ -496,7 +496,8 @@ class BigGAN(GANBase):
             return v[k]
         return v
 
-    def d_step(self, real, z=None, draws_real=None, draws_fake=None, apply=True, labels=None, cls_z=None):
+    def d_step(self, real, z=None, draws_real=None, draws_fake=None, apply=True, labels=None, cls_z=None,
+               defer=False):
         """One run of d_ops (utils.py:252-320): with --virtual_batches k, gradients of k forward/backward
         passes (each on its own real batch / z / draws; lists of k are accepted) are accumulated and
         applied once, scaled 1/k; reported losses are means over the k passes."""
@@ -510,10 +511,28 @@ class BigGAN(GANBase):
             self._sn_backward("discriminator")
             outs.append(out)
         self.store.zero_untouched("discriminator")
-        self._allreduce_grads(self.d_arena)
-        if apply:
-            self._adam(self.d_arena, self.d_learning_rate, with_ema=False, grad_scale=1.0 / vb)
+        if defer and self.world > 1:
+            # data parallel: start the all-reduce of the D gradients and return; the generator forward of the
+            # G step does not read D, so it runs while the collective is in flight and _finish_d() (wait +
+            # Adam) is called just before the G step's first use of the discriminator
+            from .parallel import allreduce_flat
+            self._pending_d = (allreduce_flat(self.d_arena.grads, self.pg, async_op=True), bool(apply), 1.0 / vb)
+        else:
+            self._allreduce_grads(self.d_arena)
+            if apply:
+                self._adam(self.d_arena, self.d_learning_rate, with_ema=False, grad_scale=1.0 / vb)
         return self._mean_losses(outs, ("d_loss", "d_cls_loss"))
+
+    def _finish_d(self):
+        pending = getattr(self, "_pending_d", None)
+        if pending is None:
+            return
+        works, apply, gscale = pending
+        self._pending_d = None
+        for w in works:
+            w.wait()
+        if apply:
+            self._adam(self.d_arena, self.d_learning_rate, with_ema=False, grad_scale=gscale)
 
     def _mean_losses(self, outs, keys):
         out = outs[-1]
@@ -526,7 +545,7 @@ class BigGAN(GANBase):
                     out[key] = Fn.axpby(acc, 0.0, acc, 1.0 / len(outs))
         return out
 
-    def g_forward(self, B, z=None, draws_fake=None, cls_z=None):
+    def g_forward(self, B, z=None, draws_fake=None, cls_z=None, after_generator=None):
         """BigGAN.py:896-898: -mean(D(aug(G(z)))) + flood (+ label loss, BigGAN.py:894) + regularisation losses."""
         self._begin_run()
         if z is None:
@@ -534,6 +553,8 @@ class BigGAN(GANBase):
         if self.acgan and cls_z is None:
             cls_z = self.synthetic_labels(B)
         fake = self.generator(z, cls_z, is_training=True)
+        if after_generator is not None:
+            after_generator()               # e.g. the deferred D update: must precede any use of the discriminator
         fake_aug = DiffAugment(fake, policy=self.da_policy, draws=draws_fake, generator=self.gen)
         d_out = self.discriminator(fake_aug)
         fake_logits = d_out["real"]
@@ -547,14 +568,15 @@ class BigGAN(GANBase):
         out["regs"] = ops.get_regularization_losses() if self.g_regularization_method != 'none' else []
         return out
 
-    def g_step(self, B, z=None, draws_fake=None, apply=True, cls_z=None):
+    def g_step(self, B, z=None, draws_fake=None, apply=True, cls_z=None, after_generator=None):
         vb = self.virtual_batches
         self._set_requires_grad(self.d_vars, False)        # g_loss is minimised over g_vars only
         outs = []
         try:
             self.store.begin_backward("generator")
             for k in range(vb):
-                out = self.g_forward(B, self._per_virtual_batch(k, z), self._per_virtual_batch(k, draws_fake), cls_z)
+                out = self.g_forward(B, self._per_virtual_batch(k, z), self._per_virtual_batch(k, draws_fake), cls_z,
+                                     after_generator if k == 0 else None)
                 roots = [out["g_adv"]] + out["regs"]
                 ones = torch.ones(1, dtype=torch.float32, device=self.device)
                 # each regularisation term is evaluated on exactly one rank (_shard_regularisers): weight 1,
@@ -584,11 +606,13 @@ class BigGAN(GANBase):
         first = real[0] if isinstance(real, (list, tuple)) else real
         if self.acgan and labels is None:
             labels = [self.synthetic_labels(first.shape[0]) for _ in range(self.virtual_batches)]
-        d = self.d_step(real, labels=labels)
+        run_g = (self.counter - 1) % self.n_critic == 0                               # BigGAN.py:1080
+        d = self.d_step(real, labels=labels, defer=run_g)
         losses["d_loss"] = d["d_loss"]
-        if (self.counter - 1) % self.n_critic == 0:                                    # BigGAN.py:1080
-            g = self.g_step(first.shape[0])
+        if run_g:
+            g = self.g_step(first.shape[0], after_generator=self._finish_d)
             losses["g_loss"] = g["g_loss"]
+        self._finish_d()
         self.counter += 1
         return losses
 
