@@ -249,7 +249,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         sb = {64: 32, 128: 8, 256: 2}.get(img, 1)      # ~10-20 s of CPU work on 16 cores
         note("cpu baseline (oracle, batch %d) ..." % sb)
-        cpu = cpu_baseline(img, ch, sb, 1, note)
+        cpu = cpu_baseline(img, ch, sb, 2 if img <= 128 else 1, note)
         note("cpu baseline done")
 
     if rank == 0:
