@@ -92,8 +92,12 @@ def main(argv=None):
     if args.phase == 'train':
         gan.train()
         print(" [*] Training finished!")
+    elif args.phase == 'test':
+        gan.test()
+        print(" [*] Test finished!")
     else:
-        raise NotImplementedError("--phase %s: sampling / serving are outside the MI355X hot path" % args.phase)
+        raise NotImplementedError("--phase %s (the reference's HTTP sample service) is outside the MI355X hot path"
+                                  % args.phase)
 
 
 if __name__ == '__main__':

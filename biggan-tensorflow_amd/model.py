@@ -689,6 +689,24 @@ class BigGAN(GANBase):
                 arena.params.copy_(live)
         return img
 
+    def test(self):
+        """--phase test (BigGAN.py:1372-1395): load the latest checkpoint and write ``test_num`` grids of
+        floor(sqrt(min(sample_num, batch_size)))^2 EMA samples to ``<result_dir>/<model_dir>/``."""
+        import numpy as np
+        from .utils import save_images, check_folder
+        could_load, _ = self.load(self.checkpoint_dir)
+        result_dir = os.path.join(self.args.result_dir, self.model_dir)
+        check_folder(result_dir)
+        print(" [*] Load SUCCESS" if could_load else " [!] Load failed...")
+        tot_num_samples = min(self.args.sample_num, self.batch_size)
+        dim = int(np.floor(np.sqrt(tot_num_samples)))
+        paths = []
+        for i in range(self.args.test_num):
+            samples = self.sample(B=self.batch_size).detach().cpu().numpy()
+            paths.append(save_images(samples[:dim * dim, :, :, :], [dim, dim],
+                                     result_dir + '/' + self.model_name + '_test_{}.png'.format(i)))
+        return paths
+
     # ---- checkpoints (BigGAN.py:1255-1284) ---------------------------------------------------
     def _ckpt_dir(self, checkpoint_dir):
         return os.path.join(checkpoint_dir, self.model_dir)

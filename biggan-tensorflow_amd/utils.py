@@ -31,6 +31,63 @@ def parse_int_list(str):
 
 
 ##################################################################################
+# Sample grids (utils.py:133-161)
+##################################################################################
+def inverse_transform(images):
+    """utils.py:160-161: [-1, 1] -> [0, 1]."""
+    return (images + 1.) / 2.
+
+
+def merge(images, size):
+    """utils.py:136-154: tile [n, h, w, c] images into a size[0] x size[1] grid (row-major)."""
+    import numpy as np
+    h, w = images.shape[1], images.shape[2]
+    if images.shape[3] in (3, 4):
+        c = images.shape[3]
+        img = np.zeros((h * size[0], w * size[1], c))
+        for idx, image in enumerate(images):
+            i = idx % size[1]
+            j = idx // size[1]
+            img[j * h:j * h + h, i * w:i * w + w, :] = image
+        return img
+    elif images.shape[3] == 1:
+        img = np.zeros((h * size[0], w * size[1]))
+        for idx, image in enumerate(images):
+            i = idx % size[1]
+            j = idx // size[1]
+            img[j * h:j * h + h, i * w:i * w + w] = image[:, :, 0]
+        return img
+    raise ValueError('in merge(images,size) images parameter must have dimensions: HxW or HxWx3 or HxWx4')
+
+
+def imsave(images, size, path):
+    """utils.py:156-157 (imageio.imwrite): 8-bit PNG written with zlib only (no imaging library here)."""
+    import struct
+    import zlib
+    import numpy as np
+    img = merge(images, size)
+    a = np.clip(np.rint(img * 255.0), 0, 255).astype(np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, c = a.shape
+    color_type = {1: 0, 3: 2, 4: 6}[c]
+    raw = b"".join(b"\x00" + a[r].tobytes() for r in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, color_type, 0, 0, 0)) +
+           chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+    with open(path, "wb") as f:
+        f.write(png)
+    return path
+
+
+def save_images(images, size, image_path):
+    """utils.py:133-134."""
+    return imsave(inverse_transform(images), size, image_path)
+
+
+##################################################################################
 # Regularization (utils.py:180-235)
 ##################################################################################
 def orthogonal_regularizer(scale, type='ortho'):

@@ -387,6 +387,24 @@ def test_train_loop_checkpoints_and_resumes(tmp_path):
     assert (tmp_path / gan.model_dir / "BigGAN.model-8.safetensors").exists()
 
 
+def test_phase_test_writes_sample_grids(tmp_path):
+    """--phase test (BigGAN.py:1372-1395): checkpoint -> EMA sample grids as PNG files."""
+    from tests.common import make_args
+    from biggan_tensorflow_amd import model, scope as S
+    kw = dict(img_size=64, ch=8, batch_size=4, z_dim=64, iteration=2, epoch=1, save_freq=2, test_num=2,
+              checkpoint_dir=str(tmp_path / "ckpt"), result_dir=str(tmp_path / "res"))
+    gan = model.BigGAN(make_args(**kw), store=S.VariableStore("cuda")).build_model()
+    gan.train()
+    tester = model.BigGAN(make_args(phase="test", **kw), store=S.VariableStore("cuda", seed=11)).build_model()
+    paths = tester.test()
+    assert len(paths) == 2 and tester.counter == 2
+    for pth in paths:
+        data = open(pth, "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n" and len(data) > 1000
+        w, h = int.from_bytes(data[16:20], "big"), int.from_bytes(data[20:24], "big")
+        assert (w, h) == (128, 128)                      # floor(sqrt(min(64, 4))) = 2 -> 2 x 2 grid of 64 x 64
+
+
 def test_train_loop_runs_and_loss_is_finite():
     from tests.common import make_args
     from biggan_tensorflow_amd import model, scope as S

@@ -133,6 +133,27 @@ def test_abi_rejects_null_tensors_before_any_launch():
     assert checked >= 50
 
 
+def test_sample_grid_png(tmp_path):
+    """utils.save_images (utils.py:133-161): [-1,1] images tiled row-major into a grid, 8-bit PNG."""
+    import struct
+    import zlib
+    imgs = np.zeros((4, 2, 3, 3), np.float32) - 1.0
+    for i in range(4):
+        imgs[i, :, :, i % 3] = 1.0 if i < 3 else 0.0
+    path = utils.save_images(imgs, [2, 2], str(tmp_path / "grid.png"))
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    w, h, depth, ctype = struct.unpack(">IIBB", data[16:26])
+    assert (w, h, depth, ctype) == (6, 4, 8, 2)
+    n = struct.unpack(">I", data[33:37])[0]
+    assert data[37:41] == b"IDAT"
+    raw = zlib.decompress(data[41:41 + n])
+    rows = np.frombuffer(raw, np.uint8).reshape(4, 1 + 6 * 3)[:, 1:].reshape(4, 6, 3)
+    assert tuple(rows[0, 0]) == (255, 0, 0) and tuple(rows[0, 3]) == (0, 255, 0)      # images 0, 1 on the first row
+    assert tuple(rows[2, 0]) == (0, 0, 255) and tuple(rows[2, 3]) == (128, 0, 0)      # images 2, 3 below (0.0 -> 128)
+    assert utils.merge(imgs, [2, 2]).shape == (4, 6, 3)
+
+
 def test_out_of_scope_flags_rejected_at_build():
     for extra in (["--deep", "true"], ["--cls_embedding", "true"], ["--gan_type", "ra-dragan"], ["--g_final_layer", "true"],
                   ["--bn_type", "batch_renorm"], ["--d_cls_dense_layers", "true"]):
