@@ -634,6 +634,35 @@ class BigGAN(GANBase):
         """BigGAN.py:1015-1118 training loop (synthetic data unless ``data_fn`` is given): resume from the
         latest checkpoint of ``checkpoint_dir`` if there is one, print the losses every iteration, save
         every ``save_freq`` iterations of an epoch (rank 0 writes; replicas are identical)."""
+        loader = None
+        if data_fn is None:
+            loader = self.open_dataset()
+            if loader is not None:
+                data_fn = lambda: next(loader)                                    # noqa: E731
+        try:
+            return self._train_loop(data_fn, iterations, resume)
+        finally:
+            if loader is not None:
+                loader.close()
+
+    def open_dataset(self, root="./dataset"):
+        """BigGAN.py:195-212, 768-787: the files of ``<root>/<--dataset>/`` (+ ``--label_file``) behind the
+        reference's shuffle / decode / resize / flip / batch pipeline; None when that folder does not exist
+        (the training loop then runs on synthetic batches)."""
+        from . import data as D
+        folder = os.path.join(root, self.dataset_name)
+        if not os.path.isdir(folder):
+            return None
+        files, labels = D.load_data(self.dataset_name, self.args.label_file, self.args.weight_file,
+                                    ignore_missing=self.args.ignore_missing_labels, n_labels=self.n_labels, root=root)
+        if self.acgan and labels is None:
+            raise ValueError("--n_labels > 0 needs --label_file")
+        print("# dataset number:", len(files))
+        image_data = D.ImageData(self.img_size, self.c_dim, True, self.args.random_flip, seed=1234 + self.rank)
+        return D.BatchLoader(files, labels if self.acgan else None, self.batch_size, image_data, self.device,
+                             seed=4321, rank=self.rank, world=self.world)
+
+    def _train_loop(self, data_fn, iterations, resume):
         could_load, checkpoint_counter = (self.load(self.checkpoint_dir) if resume else (False, 0))
         if could_load:
             start_epoch = int(checkpoint_counter / self.iterations_per_epoch)
@@ -649,8 +678,11 @@ class BigGAN(GANBase):
             for idx in range(start_batch_id, self.iterations_per_epoch):
                 if iterations is not None and done >= iterations:
                     return
-                real = data_fn() if data_fn is not None else self.synthetic_batch()
-                losses = self.train_step(real)
+                batch = data_fn() if data_fn is not None else self.synthetic_batch()
+                if isinstance(batch, tuple):                                       # (images, labels) with --n_labels
+                    losses = self.train_step(batch[0], labels=batch[1])
+                else:
+                    losses = self.train_step(batch)
                 done += 1
                 vals = {k: float(v.item()) for k, v in losses.items()}
                 print_str = "Step: %5d, time: %4.4f" % (self.counter, time.time() - start_time)   # BigGAN.py:1109-1116

@@ -405,6 +405,27 @@ def test_phase_test_writes_sample_grids(tmp_path):
         assert (w, h) == (128, 128)                      # floor(sqrt(min(64, 4))) = 2 -> 2 x 2 grid of 64 x 64
 
 
+def test_train_on_a_png_folder(tmp_path):
+    """The reference's custom-dataset path (BigGAN.py:195-212, 768-787): ./dataset/<name>/*.png -> decode, TF1
+    bilinear resize to img_size, flip, [-1, 1], shuffled batches on the device; two iterations train on it."""
+    from tests.common import make_args
+    from biggan_tensorflow_amd import model, scope as S, utils
+    folder = tmp_path / "dataset" / "toy"
+    folder.mkdir(parents=True)
+    rng = np.random.default_rng(3)
+    for i in range(8):
+        utils.save_images(rng.uniform(-1, 1, (1, 80, 80, 3)).astype(np.float32), [1, 1], str(folder / ("%d.png" % i)))
+    gan = model.BigGAN(make_args(img_size=64, ch=8, batch_size=4, z_dim=64, iteration=2, epoch=1, dataset="toy",
+                                 checkpoint_dir=str(tmp_path / "ckpt")), store=S.VariableStore("cuda")).build_model()
+    loader = gan.open_dataset(root=str(tmp_path / "dataset"))
+    assert loader is not None and gan.open_dataset(root=str(tmp_path / "missing")) is None
+    batch = next(loader)
+    assert batch.is_cuda and tuple(batch.shape) == (4, 64, 64, 3) and -1.0 <= float(batch.min()) and float(batch.max()) <= 1.0
+    gan.train(data_fn=lambda: next(loader), resume=False)
+    loader.close()
+    assert gan.counter == 2
+
+
 def test_train_loop_runs_and_loss_is_finite():
     from tests.common import make_args
     from biggan_tensorflow_amd import model, scope as S

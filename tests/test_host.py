@@ -285,3 +285,109 @@ def test_bench_flop_model_matches_baseline_md():
     for (img, ch), gf in {(128, 64): 96.24, (128, 96): 212.16, (256, 96): 713.44, (512, 128): 2376.77,
                           (64, 32): 4.74}.items():
         assert round(bench.step_flops_per_image(img, ch)[0] / 1e9, 2) == gf
+
+
+# ----------------------------------------------------------------------------------
+# input pipeline (utils.py:12-121, BigGAN.py:768-787)
+# ----------------------------------------------------------------------------------
+def _png_with_filters(img, filters):
+    """Encode an 8-bit RGB image using the given PNG filter type per row (test helper)."""
+    import struct
+    import zlib
+    h, w, c = img.shape
+    raw = b""
+    prev = np.zeros(w * c, np.int32)
+    for r in range(h):
+        line = img[r].reshape(-1).astype(np.int32)
+        ft = filters[r % len(filters)]
+        out = np.zeros_like(line)
+        for i in range(w * c):
+            left = line[i - c] if i >= c else 0
+            up = prev[i]
+            ul = prev[i - c] if i >= c else 0
+            if ft == 0:
+                pred = 0
+            elif ft == 1:
+                pred = left
+            elif ft == 2:
+                pred = up
+            elif ft == 3:
+                pred = (left + up) >> 1
+            else:
+                p = left + up - ul
+                pa, pb, pc = abs(p - left), abs(p - up), abs(p - ul)
+                pred = left if (pa <= pb and pa <= pc) else (up if pb <= pc else ul)
+            out[i] = (line[i] - pred) & 255
+        raw += bytes([ft]) + out.astype(np.uint8).tobytes()
+        prev = line
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def test_png_decoder_all_filter_types_and_channel_conversion(tmp_path):
+    from biggan_tensorflow_amd import data as D
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (7, 5, 3), dtype=np.uint8)
+    for filters in ([0], [1], [2], [3], [4], [0, 1, 2, 3, 4]):
+        assert np.array_equal(D.decode_png(_png_with_filters(img, filters), 3), img), filters
+    rgba = D.decode_png(_png_with_filters(img, [4]), 4)
+    assert rgba.shape == (7, 5, 4) and (rgba[:, :, 3] == 255).all()
+    grey = D.decode_png(_png_with_filters(img, [2]), 1)
+    ref = np.clip(np.rint(0.299 * img[:, :, 0] + 0.587 * img[:, :, 1] + 0.114 * img[:, :, 2]), 0, 255)
+    assert np.array_equal(grey[:, :, 0], ref.astype(np.uint8))
+    # the writer used for sample grids round-trips through the reader
+    x = rng.uniform(-1, 1, (1, 4, 6, 3)).astype(np.float32)
+    p = utils.save_images(x, [1, 1], str(tmp_path / "a.png"))
+    back = D.decode_png(open(p, "rb").read(), 3)
+    assert np.array_equal(back, np.clip(np.rint((x[0] + 1) / 2 * 255), 0, 255).astype(np.uint8))
+    with pytest.raises(ValueError):
+        D.decode_png(b"not a png at all", 3)
+
+
+def test_tf1_legacy_bilinear_resize():
+    """tf.image.resize_images of TF 1.x maps destination index i to source i * in/out (no half-pixel shift):
+    doubling [a, b] gives [a, (a+b)/2, b, b]; an integer reduction picks every n-th pixel."""
+    from biggan_tensorflow_amd import data as D
+    img = np.array([[[0.0], [10.0]], [[20.0], [30.0]]], np.float32)
+    up = D.resize_bilinear_legacy(img, 4)[:, :, 0]
+    assert np.allclose(up[0], [0, 5, 10, 10]) and np.allclose(up[:, 0], [0, 10, 20, 20]) and up[1, 1] == 15.0
+    big = np.arange(64, dtype=np.float32).reshape(8, 8, 1)
+    assert np.array_equal(D.resize_bilinear_legacy(big, 4)[:, :, 0], big[::2, ::2, 0])
+    assert np.array_equal(D.resize_bilinear_legacy(big, 8), big)
+
+
+def test_dataset_loader_shuffles_shards_and_labels(tmp_path):
+    from biggan_tensorflow_amd import data as D
+    folder = tmp_path / "dataset" / "toy"
+    folder.mkdir(parents=True)
+    rng = np.random.default_rng(1)
+    for i in range(12):
+        x = np.full((1, 8, 8, 3), -1.0, np.float32)
+        x[0, :, :, 0] = i / 11.0 * 2 - 1                 # file index encoded in the red channel
+        utils.save_images(x, [1, 1], str(folder / ("img%02d.png" % i)))
+    with open(tmp_path / "labels.tsv", "w") as f:
+        for i in range(12):
+            f.write("img%02d.png\t%d\t%d\n" % (i, i % 2, 1 - i % 2))
+    files, labels = D.load_data("toy", str(tmp_path / "labels.tsv"), n_labels=2, root=str(tmp_path / "dataset"))
+    assert len(files) == 12 and labels[3] == [1.0, 0.0]
+    seen = []
+    for rank in range(2):
+        idata = D.ImageData(4, 3, True, flip=False)
+        ld = D.BatchLoader(files, labels, 3, idata, "cpu", seed=9, rank=rank, world=2)
+        for _ in range(2):                               # one epoch = 12 / (3 * 2) = 2 steps per rank
+            img, lab = next(ld)
+            assert tuple(img.shape) == (3, 4, 4, 3) and tuple(lab.shape) == (3, 2) and img.dtype == torch.float32
+            ids = np.rint((img[:, 0, 0, 0].numpy() + 1) / 2 * 11).astype(int)
+            assert np.array_equal(lab[:, 0].numpy(), (ids % 2).astype(np.float32))
+            seen += ids.tolist()
+        ld.close()
+    assert sorted(seen) == list(range(12))               # the two ranks' shards of one epoch partition the dataset
+    utils.save_images(np.zeros((1, 8, 8, 3), np.float32), [1, 1], str(folder / "unlabelled.png"))
+    with pytest.raises(RuntimeError):                    # utils.py:114: "No label found for file"
+        D.load_data("toy", str(tmp_path / "labels.tsv"), n_labels=2, root=str(tmp_path / "dataset"))
+    files2, labels2 = D.load_data("toy", str(tmp_path / "labels.tsv"), ignore_missing=True, n_labels=2,
+                                  root=str(tmp_path / "dataset"))
+    assert len(files2) == 13 and labels2[-1] == [0.0, 0.0]
