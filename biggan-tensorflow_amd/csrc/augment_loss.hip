@@ -354,6 +354,146 @@ __global__ __launch_bounds__(AL_BLOCK) void ortho_lowrank_finish_kernel(float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// General (non-penalty) GAN losses (ops.py:753-840): lsgan, gan, ra-lsgan, ra-gan, ra-hinge (+ hinge).
+//   u_i = real_i - m_f, v_j = fake_j - m_r with m = batch means for the relativistic ("ra-") kinds, else u = real,
+//   v = fake;  L = mean_i phi_r(u_i) + mean_j phi_f(v_j), flooded.  phi per (kind, D / G):
+//     hinge    D: relu(1-u), relu(1+v)            G: -, -v
+//     lsgan    D: (u-1)^2,  v^2                   G: -, (v-1)^2
+//     gan      D: softplus(-u), softplus(v)       G: -, softplus(-v)
+//     ra-lsgan D: (u-1)^2, (v+1)^2                G: (u+1)^2, (v-1)^2
+//     ra-gan   D: softplus(-u), softplus(v)       G: softplus(u), softplus(-v)
+//     ra-hinge D: relu(1-u), relu(1+v)            G: relu(1+u), relu(1-v)
+//   Gradients include the coupling through the means: dL/dreal_i = (phi_r'(u_i) - mean_j phi_f'(v_j)) / N_r.
+// Single-block kernels (logits are [B, 1]); sums are exchanged across data-parallel ranks by the caller.
+// ------------------------------------------------------------------------------------------
+enum { GL_HINGE = 0, GL_LSGAN = 1, GL_GAN = 2, GL_RA_LSGAN = 3, GL_RA_GAN = 4, GL_RA_HINGE = 5 };
+
+__device__ __forceinline__ float gl_softplus(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
+__device__ __forceinline__ float gl_sigmoid(float x) {
+    const float e = __expf(-fabsf(x));
+    return x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+}
+
+// value and derivative of the real-side / fake-side term
+__device__ __forceinline__ void gl_phi(int kind, int gen, bool real_side, float x, float* val, float* der) {
+    const bool ra = kind >= GL_RA_LSGAN;
+    if (real_side && gen && !ra) {          // non-relativistic generator losses do not look at the real logits
+        *val = 0.f;
+        *der = 0.f;
+        return;
+    }
+    // sign convention: s = +1 -> "push x up" form, s = -1 -> "push x down" form
+    //   D real, G fake : wants x large  -> relu(1 - x), (x - 1)^2, softplus(-x)
+    //   D fake, G real : wants x small  -> relu(1 + x), (x + 1)^2 (ra) / x^2 (lsgan), softplus(x)
+    const bool up = (real_side != (gen != 0));
+    switch (kind) {
+        case GL_HINGE:
+        case GL_RA_HINGE:
+            if (kind == GL_HINGE && gen) {   // ops.py:832-833: -mean(fake)
+                *val = -x;
+                *der = -1.f;
+            } else if (up) {
+                *val = fmaxf(1.f - x, 0.f);
+                *der = (1.f - x) > 0.f ? -1.f : 0.f;
+            } else {
+                *val = fmaxf(1.f + x, 0.f);
+                *der = (1.f + x) > 0.f ? 1.f : 0.f;
+            }
+            break;
+        case GL_LSGAN:
+        case GL_RA_LSGAN: {
+            const float t = up ? 1.f : (kind == GL_RA_LSGAN ? -1.f : 0.f);
+            *val = (x - t) * (x - t);
+            *der = 2.f * (x - t);
+            break;
+        }
+        default:                            // GL_GAN, GL_RA_GAN: sigmoid cross-entropy with label 1 (up) / 0 (down)
+            if (up) {
+                *val = gl_softplus(-x);
+                *der = -gl_sigmoid(-x);
+            } else {
+                *val = gl_softplus(x);
+                *der = gl_sigmoid(x);
+            }
+    }
+}
+
+// sums[0] = sum real, sums[1] = sum fake
+__global__ __launch_bounds__(AL_BLOCK) void gan_means_kernel(const float* real, const float* fake, float* sums, int nr,
+                                                              int nf) {
+    __shared__ float sh[4];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < nr; i += AL_BLOCK) a += real[i];
+    for (int i = threadIdx.x; i < nf; i += AL_BLOCK) b += fake[i];
+    a = block_sum_256(a, sh);
+    b = block_sum_256(b, sh);
+    if (threadIdx.x == 0) {
+        sums[0] = a;
+        sums[1] = b;
+    }
+}
+
+// tsums = {sum phi_r, sum phi_f, sum phi_r', sum phi_f'} given the GLOBAL means
+__global__ __launch_bounds__(AL_BLOCK) void gan_terms_kernel(int kind, int gen, const float* real, const float* fake,
+                                                              const float* sums, double nr_g, double nf_g, float* tsums,
+                                                              int nr, int nf) {
+    __shared__ float sh[4];
+    const bool ra = kind >= GL_RA_LSGAN;
+    const float mr = ra && nr_g > 0 ? (float)(sums[0] / nr_g) : 0.f;
+    const float mf = ra && nf_g > 0 ? (float)(sums[1] / nf_g) : 0.f;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < nr; i += AL_BLOCK) {
+        float v, d;
+        gl_phi(kind, gen, true, real[i] - mf, &v, &d);
+        t[0] += v;
+        t[2] += d;
+    }
+    for (int i = threadIdx.x; i < nf; i += AL_BLOCK) {
+        float v, d;
+        gl_phi(kind, gen, false, fake[i] - mr, &v, &d);
+        t[1] += v;
+        t[3] += d;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float s = block_sum_256(t[q], sh);
+        if (threadIdx.x == 0) tsums[q] = s;
+    }
+}
+
+__global__ __launch_bounds__(AL_BLOCK) void gan_grad_kernel(int kind, int gen, const float* real, const float* fake,
+                                                             const float* sums, const float* tsums, double nr_g,
+                                                             double nf_g, float flood, float* d_real, float* d_fake,
+                                                             float* loss_out, int nr, int nf) {
+    const bool ra = kind >= GL_RA_LSGAN;
+    const bool use_real = !(gen && !ra) && nr_g > 0;
+    const float inv_r = use_real ? (float)(1.0 / nr_g) : 0.f, inv_f = (float)(1.0 / nf_g);
+    const float mr = ra && nr_g > 0 ? (float)(sums[0] / nr_g) : 0.f;
+    const float mf = ra ? (float)(sums[1] / nf_g) : 0.f;
+    float L = tsums[0] * inv_r + tsums[1] * inv_f;
+    float sgn = 1.f;
+    if (flood != 0.f) {                                         // ops.py:794-795, 837-838
+        const float d = L - flood;
+        sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        L = fabsf(d) + flood;
+    }
+    if (threadIdx.x == 0 && loss_out) *loss_out = L;
+    const float cross_r = ra ? tsums[3] * inv_f : 0.f;          // mean_j phi_f'(v_j): reaches real through m_r
+    const float cross_f = ra ? tsums[2] * inv_r : 0.f;
+    if (d_real)
+        for (int i = threadIdx.x; i < nr; i += AL_BLOCK) {
+            float v, d;
+            gl_phi(kind, gen, true, real[i] - mf, &v, &d);
+            d_real[i] = sgn * (d - cross_r) * inv_r;
+        }
+    for (int i = threadIdx.x; i < nf; i += AL_BLOCK) {
+        float v, d;
+        gl_phi(kind, gen, false, fake[i] - mr, &v, &d);
+        d_fake[i] = sgn * (d - cross_f) * inv_f;
+    }
+}
+
 // plain 'ortho' regulariser (utils.py:199-200): reg = A - I, loss = scale * l2_loss(reg), dA = scale * reg
 __global__ __launch_bounds__(AL_BLOCK) void ortho_identity_kernel(const float* __restrict__ A, float scale,
                                                                    float* loss_accum, float* __restrict__ dA, int c) {
@@ -501,6 +641,35 @@ int bg_ortho_lowrank_finish(float* dW, const float* P, const float* s, const flo
 int bg_ortho_cosine_fwd_bwd(const float* A, float scale, float* loss_accum, float* dA, int c, void* stream) {
     BG_REQUIRE(A && loss_accum && c > 0, "bg_ortho_cosine_fwd_bwd: bad argument");
     hipLaunchKernelGGL(ortho_cosine_kernel, dim3(c), dim3(AL_BLOCK), 0, as_stream(stream), A, scale, loss_accum, dA, c);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_gan_loss_means(const float* real, const float* fake, float* sums, int nr, int nf, void* stream) {
+    BG_REQUIRE(fake && sums && nf > 0 && nr >= 0 && (nr == 0 || real), "bg_gan_loss_means: bad argument");
+    hipLaunchKernelGGL(gan_means_kernel, dim3(1), dim3(AL_BLOCK), 0, as_stream(stream), real, fake, sums, nr, nf);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_gan_loss_terms(int kind, int generator, const float* real, const float* fake, const float* sums,
+                      double n_real_global, double n_fake_global, float* tsums, int nr, int nf, void* stream) {
+    BG_REQUIRE(kind >= 0 && kind <= 5 && fake && sums && tsums && nf > 0 && nr >= 0 && (nr == 0 || real) &&
+                   n_fake_global > 0, "bg_gan_loss_terms: bad argument");
+    hipLaunchKernelGGL(gan_terms_kernel, dim3(1), dim3(AL_BLOCK), 0, as_stream(stream), kind, generator, real, fake,
+                       sums, n_real_global, n_fake_global, tsums, nr, nf);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_gan_loss_grad(int kind, int generator, const float* real, const float* fake, const float* sums,
+                     const float* tsums, double n_real_global, double n_fake_global, float flood, float* d_real,
+                     float* d_fake, float* loss_out, int nr, int nf, void* stream) {
+    BG_REQUIRE(kind >= 0 && kind <= 5 && fake && sums && tsums && d_fake && nf > 0 && nr >= 0 &&
+                   (nr == 0 || (real && d_real)) && n_fake_global > 0, "bg_gan_loss_grad: bad argument");
+    hipLaunchKernelGGL(gan_grad_kernel, dim3(1), dim3(AL_BLOCK), 0, as_stream(stream), kind, generator, real, fake,
+                       sums, tsums, n_real_global, n_fake_global, flood, nr ? d_real : nullptr, d_fake, loss_out, nr,
+                       nf);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -831,6 +831,53 @@ class HingeGLossFn(Function):
         return df, None, None, None
 
 
+GAN_LOSS_KINDS = {"hinge": 0, "lsgan": 1, "gan": 2, "ra-lsgan": 3, "ra-gan": 4, "ra-hinge": 5}
+
+
+class GanLossFn(Function):
+    """discriminator_loss / generator_loss for the non-penalty loss types (ops.py:753-840):
+    lsgan, gan, ra-lsgan, ra-gan, ra-hinge (hinge too; the model uses the dedicated hinge kernels for it)."""
+
+    @staticmethod
+    def forward(ctx, real, fake, kind, generator, flood, reduce_fn, world):
+        fake = _c(fake)
+        nf = fake.numel()
+        nr = 0 if real is None else real.numel()
+        real = None if real is None else _c(real)
+        L = lib()
+        dev = fake.device
+        sums = torch.zeros(2, dtype=torch.float32, device=dev)
+        check(L.bg_gan_loss_means(f32(real), f32(fake), f32(sums), nr, nf, stream()))
+        if reduce_fn is not None:
+            reduce_fn(sums)
+        tsums = torch.zeros(4, dtype=torch.float32, device=dev)
+        check(L.bg_gan_loss_terms(kind, int(generator), f32(real), f32(fake), f32(sums), float(nr * world),
+                                  float(nf * world), f32(tsums), nr, nf, stream()))
+        if reduce_fn is not None:
+            reduce_fn(tsums)
+        d_real = None if real is None else torch.empty_like(real)
+        d_fake = torch.empty_like(fake)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        check(L.bg_gan_loss_grad(kind, int(generator), f32(real), f32(fake), f32(sums), f32(tsums), float(nr * world),
+                                 float(nf * world), float(flood or 0.0), f32(d_real), f32(d_fake), f32(loss), nr, nf,
+                                 stream()))
+        ctx.d_real, ctx.d_fake = d_real, d_fake
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        outs = []
+        for d, need in ((ctx.d_real, ctx.needs_input_grad[0]), (ctx.d_fake, ctx.needs_input_grad[1])):
+            if d is None or not need:
+                outs.append(None)
+                continue
+            o = torch.empty_like(d)
+            check(lib().bg_scale_dev(f32(d), f32(g), f32(o), o.numel(), stream()))
+            outs.append(o)
+        return outs[0], outs[1], None, None, None, None, None
+
+
 class SigmoidCeLossFn(Function):
     """cls_loss_fn('logistic', w)(truth, answer) * loss_weight (utils.py:366-369, BigGAN.py:853,894):
     mean over the GLOBAL batch x labels of the weighted sigmoid cross-entropy."""

@@ -106,6 +106,10 @@ SIGNATURES = {
     "bg_hinge_d_grad": (c_int, [_P, _P, _P, c_double, c_float, _P, _P, _P, c_int, _P]),
     "bg_hinge_g_sums": (c_int, [_P, _P, c_int, _P]),
     "bg_hinge_g_grad": (c_int, [_P, c_double, c_float, _P, _P, c_int, _P]),
+    "bg_gan_loss_means": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "bg_gan_loss_terms": (c_int, [c_int, c_int, _P, _P, _P, c_double, c_double, _P, c_int, c_int, _P]),
+    "bg_gan_loss_grad": (c_int, [c_int, c_int, _P, _P, _P, _P, c_double, c_double, c_float, _P, _P, _P, c_int, c_int,
+                                 _P]),
     "bg_sigmoid_ce": (c_int, [_P, _P, _P, c_float, _P, _P, c_int, c_int, _P]),
     "bg_ortho_cosine_fwd_bwd": (c_int, [_P, c_float, _P, _P, c_int, _P]),
     "bg_ortho_identity_fwd_bwd": (c_int, [_P, c_float, _P, _P, c_int, _P]),

@@ -75,9 +75,11 @@ class BigGAN(GANBase):
             raise NotImplementedError("flags outside the MI355X hot path (SURVEY.md section 8): " + ", ".join(bad))
         self.gan_type = args.gan_type
         self.d_loss_func = args.d_loss_func if args.d_loss_func else self.gan_type     # BigGAN.py:127-128
-        if self.gan_type != 'hinge' or self.d_loss_func != 'hinge':
-            raise NotImplementedError("only --gan_type hinge is on the hot path (got %s / %s)"
-                                      % (self.gan_type, self.d_loss_func))
+        if self.gan_type not in Fn.GAN_LOSS_KINDS or self.d_loss_func not in Fn.GAN_LOSS_KINDS:
+            raise NotImplementedError("--gan_type / --d_loss_func %s / %s: the gradient-penalty losses (wgan-gp, wgan-lp, "
+                                      "dragan, ra-dragan) need double backward and are not implemented; available: %s"
+                                      % (self.gan_type, self.d_loss_func, ", ".join(sorted(Fn.GAN_LOSS_KINDS))))
+        self.relativistic = self.gan_type.startswith('ra-')
 
         self.activation = args.activation                                              # BigGAN.py:71-83
         if self.activation == 'relu':
@@ -545,7 +547,7 @@ class BigGAN(GANBase):
                     out[key] = Fn.axpby(acc, 0.0, acc, 1.0 / len(outs))
         return out
 
-    def g_forward(self, B, z=None, draws_fake=None, cls_z=None, after_generator=None):
+    def g_forward(self, B, z=None, draws_fake=None, cls_z=None, after_generator=None, real=None, draws_real=None):
         """BigGAN.py:896-898: -mean(D(aug(G(z)))) + flood (+ label loss, BigGAN.py:894) + regularisation losses."""
         self._begin_run()
         if z is None:
@@ -556,9 +558,27 @@ class BigGAN(GANBase):
         if after_generator is not None:
             after_generator()               # e.g. the deferred D update: must precede any use of the discriminator
         fake_aug = DiffAugment(fake, policy=self.da_policy, draws=draws_fake, generator=self.gen)
-        d_out = self.discriminator(fake_aug)
-        fake_logits = d_out["real"]
-        g_adv = generator_loss(self.gan_type, fake=fake_logits, real=None, flood_level=self.g_flood)
+        real_logits = None
+        if self.relativistic:
+            # g_loss of the ra-* types reads D(aug(real)) too (BigGAN.py:806-808, 896); D's weights are frozen
+            # in this op, so the real half needs no backward graph
+            if real is None:
+                raise ValueError("--gan_type %s: the G step needs a real batch" % self.gan_type)
+            real_aug = DiffAugment(real, policy=self.da_policy, draws=draws_real, generator=self.gen)
+            if self.bn_in_d:
+                real_logits = self.discriminator(real_aug)["real"]
+                d_out = self.discriminator(fake_aug, reuse=True)
+                fake_logits = d_out["real"]
+            else:
+                d_out = self.discriminator(torch.cat([real_aug, fake_aug], dim=0))
+                nr = real_aug.shape[0]
+                real_logits, fake_logits = d_out["real"][:nr], d_out["real"][nr:]
+                if self.acgan:
+                    d_out = dict(d_out, cls=d_out["cls"][nr:])
+        else:
+            d_out = self.discriminator(fake_aug)
+            fake_logits = d_out["real"]
+        g_adv = generator_loss(self.gan_type, fake=fake_logits, real=real_logits, flood_level=self.g_flood)
         out = {"fake_logits": fake_logits, "fake": fake}
         if self.acgan:
             g_cls = self._cls_loss()(cls_z, d_out["cls"], self.g_cls_loss_weight, self._reduce_fn(), self.world)
@@ -568,7 +588,8 @@ class BigGAN(GANBase):
         out["regs"] = ops.get_regularization_losses() if self.g_regularization_method != 'none' else []
         return out
 
-    def g_step(self, B, z=None, draws_fake=None, apply=True, cls_z=None, after_generator=None):
+    def g_step(self, B, z=None, draws_fake=None, apply=True, cls_z=None, after_generator=None, real=None,
+               draws_real=None):
         vb = self.virtual_batches
         self._set_requires_grad(self.d_vars, False)        # g_loss is minimised over g_vars only
         outs = []
@@ -576,7 +597,8 @@ class BigGAN(GANBase):
             self.store.begin_backward("generator")
             for k in range(vb):
                 out = self.g_forward(B, self._per_virtual_batch(k, z), self._per_virtual_batch(k, draws_fake), cls_z,
-                                     after_generator if k == 0 else None)
+                                     after_generator if k == 0 else None, self._per_virtual_batch(k, real),
+                                     self._per_virtual_batch(k, draws_real))
                 roots = [out["g_adv"]] + out["regs"]
                 ones = torch.ones(1, dtype=torch.float32, device=self.device)
                 # each regularisation term is evaluated on exactly one rank (_shard_regularisers): weight 1,
@@ -610,7 +632,8 @@ class BigGAN(GANBase):
         d = self.d_step(real, labels=labels, defer=run_g)
         losses["d_loss"] = d["d_loss"]
         if run_g:
-            g = self.g_step(first.shape[0], after_generator=self._finish_d)
+            # (the reference's g_ops pull a fresh real batch from the input iterator; the D step's batch is reused here)
+            g = self.g_step(first.shape[0], after_generator=self._finish_d, real=real if self.relativistic else None)
             losses["g_loss"] = g["g_loss"]
         self._finish_d()
         self.counter += 1

@@ -613,16 +613,24 @@ def spectral_norm(w, iteration=1, _shape_only=False):
 ##################################################################################
 def discriminator_loss(loss_func, real, fake, flood_level=0):
     """ops.py:753-797 ('hinge' branch)."""
-    if loss_func != 'hinge':
-        raise NotImplementedError("discriminator_loss('%s'): only --gan_type hinge is on the hot path" % loss_func)
-    return Fn.HingeDLossFn.apply(real, fake, flood_level, _run.reduce_fn, _run.world)
+    if loss_func == 'hinge':
+        return Fn.HingeDLossFn.apply(real, fake, flood_level, _run.reduce_fn, _run.world)
+    if loss_func in Fn.GAN_LOSS_KINDS:
+        return Fn.GanLossFn.apply(real, fake, Fn.GAN_LOSS_KINDS[loss_func], 0, flood_level, _run.reduce_fn, _run.world)
+    raise NotImplementedError("discriminator_loss('%s'): gradient-penalty losses (wgan-gp, wgan-lp, dragan, "
+                              "ra-dragan) need double backward and are not implemented" % loss_func)
 
 
 def generator_loss(loss_func, fake, real, flood_level=0):
     """ops.py:799-840 ('hinge' branch)."""
-    if loss_func != 'hinge':
-        raise NotImplementedError("generator_loss('%s'): only --gan_type hinge is on the hot path" % loss_func)
-    return Fn.HingeGLossFn.apply(fake, flood_level, _run.reduce_fn, _run.world)
+    if loss_func == 'hinge':
+        return Fn.HingeGLossFn.apply(fake, flood_level, _run.reduce_fn, _run.world)
+    if loss_func in Fn.GAN_LOSS_KINDS:
+        if loss_func.startswith('ra-') and real is None:
+            raise ValueError("generator_loss('%s') is relativistic: it needs the real logits" % loss_func)
+        r = real if loss_func.startswith('ra-') else None
+        return Fn.GanLossFn.apply(r, fake, Fn.GAN_LOSS_KINDS[loss_func], 1, flood_level, _run.reduce_fn, _run.world)
+    raise NotImplementedError("generator_loss('%s'): gradient-penalty losses are not implemented" % loss_func)
 
 
 def glu(x, opt=None):

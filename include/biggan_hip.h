@@ -272,6 +272,19 @@ int bg_hinge_g_sums(const float* fake, float* sums, int n, void* stream);
 int bg_hinge_g_grad(const float* sums, double n_global, float flood, float* d_fake, float* loss_out,
                     int n, void* stream);
 
+/* General non-penalty GAN losses (ops.py:753-840): kind 0 hinge, 1 lsgan, 2 gan, 3 ra-lsgan, 4 ra-gan,
+ * 5 ra-hinge; generator = 0 for discriminator_loss, 1 for generator_loss.  Three steps so that data-parallel
+ * ranks can exchange the sums in between:  bg_gan_loss_means -> sums = {sum real, sum fake};
+ * bg_gan_loss_terms (given the GLOBAL sums / counts) -> tsums = {sum phi_r, sum phi_f, sum phi_r', sum phi_f'};
+ * bg_gan_loss_grad (given the GLOBAL tsums) -> loss (flooded), d_real, d_fake (incl. the coupling through the
+ * batch means of the relativistic kinds).  real may be NULL with nr = 0 (non-relativistic generator losses). */
+int bg_gan_loss_means(const float* real, const float* fake, float* sums, int nr, int nf, void* stream);
+int bg_gan_loss_terms(int kind, int generator, const float* real, const float* fake, const float* sums,
+                      double n_real_global, double n_fake_global, float* tsums, int nr, int nf, void* stream);
+int bg_gan_loss_grad(int kind, int generator, const float* real, const float* fake, const float* sums,
+                     const float* tsums, double n_real_global, double n_fake_global, float flood, float* d_real,
+                     float* d_fake, float* loss_out, int nr, int nf, void* stream);
+
 /* Class-label loss of the conditional model (utils.py:366-369, BigGAN.py:853,894), 'logistic' type:
  *   loss = scale * sum_{b,j} sigmoid_cross_entropy_with_logits(truth, logits)[b,j] * weights[j]
  *   dlogits = scale * weights[j] * (sigmoid(logits) - truth);  scale = loss_weight / (global_batch * n).

@@ -267,7 +267,7 @@ class Trainer:
         cz = self._t(cls_z) if cfg.n_labels else None
         fake = generator(vs, cfg, self._t(z), cz, True)                             # :883
         d_fake = discriminator(vs, cfg, R.diffaugment(fake, aug_fake, cfg.da_policy))   # :857
-        d_loss = R.discriminator_loss("hinge", d_real["real"], d_fake["real"], cfg.d_flood)  # :879
+        d_loss = R.discriminator_loss(cfg.gan_type, d_real["real"], d_fake["real"], cfg.d_flood)  # :879
         d_cls = None
         if cfg.n_labels:
             w = torch.ones(cfg.n_labels, dtype=self.dtype)
@@ -276,14 +276,17 @@ class Trainer:
         return {"d_loss": d_loss, "real_logits": d_real["real"], "fake_logits": d_fake["real"],
                 "fake": fake, "d_cls_loss": d_cls}
 
-    def g_forward(self, z, aug_fake, cls_z=None):
+    def g_forward(self, z, aug_fake, cls_z=None, real=None, aug_real=None):
         cfg, vs = self.cfg, self.vs
         vs.reg_losses = []
         vs.state_updates.clear()
+        real_logits = None
+        if cfg.gan_type.startswith("ra-"):      # relativistic: g_loss reads D(aug(real)) as well (BigGAN.py:806-808,896)
+            real_logits = discriminator(vs, cfg, R.diffaugment(self._t(real), aug_real, cfg.da_policy))["real"]
         cz = self._t(cls_z) if cfg.n_labels else None
         fake = generator(vs, cfg, self._t(z), cz, True)
         d_fake = discriminator(vs, cfg, R.diffaugment(fake, aug_fake, cfg.da_policy))
-        g_adv = R.generator_loss("hinge", d_fake["real"], None, cfg.g_flood)        # BigGAN.py:896
+        g_adv = R.generator_loss(cfg.gan_type, d_fake["real"], real_logits, cfg.g_flood)   # BigGAN.py:896
         g_loss = g_adv
         g_cls = None
         if cfg.n_labels:
@@ -329,8 +332,8 @@ class Trainer:
         out["grads"] = gd
         return out
 
-    def g_step(self, z, aug_fake, cls_z=None, apply=True):
-        out = self.g_forward(z, aug_fake, cls_z)
+    def g_step(self, z, aug_fake, cls_z=None, apply=True, real=None, aug_real=None):
+        out = self.g_forward(z, aug_fake, cls_z, real, aug_real)
         params = self.g_params()
         grads = torch.autograd.grad(out["g_loss"], list(params.values()), allow_unused=True)
         gd = OrderedDict((k, (g if g is not None else torch.zeros_like(p)))

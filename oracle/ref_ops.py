@@ -464,19 +464,57 @@ def flood_loss(loss, flood_level):                # ops.py:847-848
     return (loss - flood_level).abs() + flood_level
 
 
+def _sce(labels_one, logits):
+    """tf.nn.sigmoid_cross_entropy_with_logits with labels all ones (True) or all zeros (False)."""
+    return F.softplus(-logits) if labels_one else F.softplus(logits)
+
+
 def discriminator_loss(loss_func, real, fake, flood_level=0):
-    if loss_func != "hinge":
+    """ops.py:753-797 (the loss types without a gradient penalty)."""
+    if loss_func == "lsgan":
+        real_loss, fake_loss = ((real - 1.0) ** 2).mean(), (fake ** 2).mean()
+    elif loss_func == "ra-lsgan":
+        d_xr, d_xf = real - fake.mean(), fake - real.mean()
+        real_loss, fake_loss = ((d_xr - 1.0) ** 2).mean(), ((d_xf + 1.0) ** 2).mean()
+    elif loss_func == "gan":
+        real_loss, fake_loss = _sce(True, real).mean(), _sce(False, fake).mean()
+    elif loss_func == "ra-gan":
+        d_xr, d_xf = real - fake.mean(), fake - real.mean()
+        real_loss, fake_loss = _sce(True, d_xr).mean(), _sce(False, d_xf).mean()
+    elif loss_func == "ra-hinge":
+        d_xr, d_xf = real - fake.mean(), fake - real.mean()
+        real_loss, fake_loss = torch.relu(1.0 - d_xr).mean(), torch.relu(1.0 + d_xf).mean()
+    elif loss_func == "hinge":
+        real_loss, fake_loss = torch.relu(1.0 - real).mean(), torch.relu(1.0 + fake).mean()   # ops.py:788-790
+    else:
         raise NotImplementedError(loss_func)
-    loss = torch.relu(1.0 - real).mean() + torch.relu(1.0 + fake).mean()   # ops.py:788-790
+    loss = real_loss + fake_loss
     if flood_level:
         loss = flood_loss(loss, flood_level)                                # ops.py:794-795
     return loss
 
 
 def generator_loss(loss_func, fake, real=None, flood_level=0):
-    if loss_func != "hinge":
+    """ops.py:799-840."""
+    real_loss = 0.0
+    if loss_func == "lsgan":
+        fake_loss = ((fake - 1.0) ** 2).mean()
+    elif loss_func == "ra-lsgan":
+        d_xr, d_xf = real - fake.mean(), fake - real.mean()
+        real_loss, fake_loss = ((d_xr + 1.0) ** 2).mean(), ((d_xf - 1.0) ** 2).mean()
+    elif loss_func == "gan":
+        fake_loss = _sce(True, fake).mean()
+    elif loss_func == "ra-gan":
+        d_xr, d_xf = real - fake.mean(), fake - real.mean()
+        fake_loss, real_loss = _sce(True, d_xf).mean(), _sce(False, d_xr).mean()
+    elif loss_func == "ra-hinge":
+        d_xr, d_xf = real - fake.mean(), fake - real.mean()
+        real_loss, fake_loss = torch.relu(1.0 - d_xf).mean(), torch.relu(1.0 + d_xr).mean()
+    elif loss_func == "hinge":
+        fake_loss = -fake.mean()                                            # ops.py:832-833
+    else:
         raise NotImplementedError(loss_func)
-    loss = -fake.mean()                                                     # ops.py:832-833
+    loss = fake_loss + real_loss
     if flood_level:
         loss = flood_loss(loss, flood_level)                                # ops.py:837-838
     return loss

@@ -602,6 +602,27 @@ def test_hinge_losses_with_flood(scale):
     assert rel_err(t2n(fc2.grad), ft2.grad.numpy()) < 1e-6     # includes the flood sign flip
 
 
+@pytest.mark.parametrize("kind", ["hinge", "lsgan", "gan", "ra-lsgan", "ra-gan", "ra-hinge"])
+@pytest.mark.parametrize("flood", [0.0, 0.3, 5.0])
+def test_general_gan_losses(kind, flood):
+    """ops.py:753-840 through bg_gan_loss_*: values and gradients of D and G losses, with the flood sign flip."""
+    Fn = _fn()
+    rng = np.random.default_rng(len(kind))
+    real, fake = rng.standard_normal((7, 1)) * 1.5 + 0.2, rng.standard_normal((5, 1)) * 1.5 - 0.1
+    for gen in (0, 1):
+        rt, ft = torch.tensor(real, requires_grad=True), torch.tensor(fake, requires_grad=True)
+        ref = (R.generator_loss(kind, ft, rt, flood) if gen else R.discriminator_loss(kind, rt, ft, flood))
+        ref.backward()
+        rc, fc = cu(real, True), cu(fake, True)
+        use_real = (not gen) or kind.startswith("ra-")
+        loss = Fn.GanLossFn.apply(rc if use_real else None, fc, Fn.GAN_LOSS_KINDS[kind], gen, flood, None, 1)
+        loss.backward()
+        assert abs(loss.item() - ref.item()) <= 2e-6 * max(abs(ref.item()), 1.0), (kind, gen, loss.item(), ref.item())
+        assert rel_err(t2n(fc.grad), ft.grad.numpy()) < 2e-5, (kind, gen)
+        if use_real and rt.grad is not None:
+            assert rel_err(t2n(rc.grad), rt.grad.numpy()) < 2e-5, (kind, gen)
+
+
 @pytest.mark.parametrize("shape", [(3, 3, 8, 16), (96, 184), (4, 4, 32, 8), (3, 3, 8, 3), (32, 320), (184, 1024),
                                    (7, 33)])
 def test_ortho_cosine_regulariser(shape):

@@ -120,11 +120,14 @@ def _run_parity(tr, gan, batch, check_state=True):
     state0 = tr.vs.export()
     hip0 = gan.store.export_arrays()
     okw_d, okw_g, hkw_d, hkw_g = {}, {}, {}, {}
+    if cfg.gan_type.startswith("ra-"):                 # relativistic losses: the G op reads D(aug(real)) too
+        okw_g = dict(real=batch["real"], aug_real=batch["aug_real"])
+        hkw_g = dict(real=real, draws_real=a_r)
     if cfg.n_labels:                                   # class-conditional variant
         okw_d = dict(labels=batch["labels"], cls_z=batch["cls_z_d"])
-        okw_g = dict(cls_z=batch["cls_z_g"])
+        okw_g = dict(okw_g, cls_z=batch["cls_z_g"])
         hkw_d = dict(labels=cu(batch["labels"]), cls_z=cu(batch["cls_z_d"]))
-        hkw_g = dict(cls_z=cu(batch["cls_z_g"]))
+        hkw_g = dict(hkw_g, cls_z=cu(batch["cls_z_g"]))
 
     # ---------------- gradient parity, D op ----------------
     ro = tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], apply=False, **okw_d)
@@ -184,8 +187,9 @@ def _run_parity(tr, gan, batch, check_state=True):
     assert abs(ho["g_loss"].item() - ro["g_loss"].item()) <= 1e-3 * max(abs(ro["g_loss"].item()), 1e-6)
     after2 = tr.vs.export()
     hip2 = gan.store.export_arrays()
+    noise_d = {k for k in after if _noise_driven(k, rd["grads"])}    # e.g. D_logit/bias under a relativistic loss
     for k in after2:
-        if _noise_driven(k, ro["grads"]):
+        if _noise_driven(k, ro["grads"]) or k in noise_d:
             continue
         if k.endswith("/u") and after2[k].size == 1:
             pass                         # a 1-element u is +-1 up to an ulp after its first update
@@ -354,6 +358,16 @@ def test_step_parity_non_default_flags(okw, hkw):
     tr = oracle_trainer(64, 8, 64, 4, **okw)
     gan = hip_model_like(tr, **hkw)
     batch = RM.synthetic_batch(tr.cfg, 13, 4)
+    _run_parity(tr, gan, batch)
+
+
+@pytest.mark.parametrize("gan_type", ["lsgan", "gan", "ra-lsgan", "ra-gan", "ra-hinge"])
+def test_step_parity_other_gan_losses(gan_type):
+    """--gan_type lsgan / gan / ra-lsgan / ra-gan / ra-hinge (ops.py:753-840; SURVEY 8f rank 4 without the gradient
+    penalty): the relativistic types couple real and fake logits through their batch means, also in the G op."""
+    tr = oracle_trainer(64, 8, 64, 4, gan_type=gan_type)
+    gan = hip_model_like(tr, gan_type=gan_type)
+    batch = RM.synthetic_batch(tr.cfg, 17, 4)
     _run_parity(tr, gan, batch)
 
 
