@@ -20,6 +20,7 @@ from . import functional as Fn
 from . import scope as S
 from . import hip
 from .ops import (fully_connected, resblock_up_condition, resblock_down, resblock, self_attention_2, conv, bn,
+                  resblock_up_cond_deep, resblock_down_deep,
                   prelu, relu, lrelu, tanh, global_sum_pooling, discriminator_loss, generator_loss)
 from .DiffAugment import DiffAugment, draw as draw_augment
 from .utils import orthogonal_regularizer, orthogonal_regularizer_fc, l2_regularizer, round_up, cls_loss_fn
@@ -59,7 +60,7 @@ class BigGAN(GANBase):
         self.depth = args.img_size.bit_length() - 2                                   # BigGAN.py:19
 
         unsupported = [
-            ("deep", args.deep), ("cls_embedding", args.cls_embedding), ("d_cls_dense_layers", args.d_cls_dense_layers),
+            ("cls_embedding", args.cls_embedding), ("d_cls_dense_layers", args.d_cls_dense_layers),
             ("shared_z", args.shared_z > 0), ("g_z_dense_concat", args.g_z_dense_concat),
             ("g_other_level_dense_layer", args.g_other_level_dense_layer),
             ("g_no_last_resblock", args.g_no_last_resblock), ("g_mixed_resblocks", args.g_mixed_resblocks),
@@ -124,6 +125,7 @@ class BigGAN(GANBase):
         self.moving_decay = args.moving_decay
         self.d_compat_use_sn_in_critic_output = args.d_compat_use_sn_in_critic_output
         self.extension_32 = getattr(args, "extension_32", False)
+        self.deep = args.deep                                                          # BigGAN.py:20
         self.n_labels = args.n_labels                                                  # BigGAN.py:22-23
         self.acgan = self.n_labels > 0
         self.virtual_batches = max(int(args.virtual_batches), 1)
@@ -287,7 +289,12 @@ class BigGAN(GANBase):
                     layer_z, z_dim = next_z_split()
                     if block_count > 1:
                         scope = scope + '_' + str(sb_i)                                # cumulative (BigGAN.py:455)
-                    x = resblock_up_condition(x, layer_z, channels=ch, use_bias=False, opt=opt, scope=scope)
+                    if self.deep:                                                      # BigGAN.py:475-477
+                        x = resblock_up_cond_deep(x, layer_z, channels_out=ch, use_bias=True, opt=opt, scope=scope)
+                        x = resblock_up_cond_deep(x, layer_z, channels_out=ch, upscale=False, use_bias=True, opt=opt,
+                                                  scope=scope + "_2")
+                    else:
+                        x = resblock_up_condition(x, layer_z, channels=ch, use_bias=False, opt=opt, scope=scope)
                 b_i += 1
                 if b_i == block_info["sa_index"]:
                     x = self_attention_2(x, channels=ch, opt=opt, scope='self_attention')
@@ -330,7 +337,12 @@ class BigGAN(GANBase):
                 for sb_i in range(block_count):
                     if block_count > 1:
                         scope = scope + '_' + str(sb_i)
-                    x = resblock_down(x, channels=ch, use_bias=self.d_use_bias, opt=opt, scope=scope)
+                    if self.deep:                                                      # BigGAN.py:629-631
+                        x = resblock_down_deep(x, channels_out=ch, use_bias=self.d_use_bias, opt=opt, scope=scope)
+                        x = resblock_down_deep(x, channels_out=ch, downscale=False, use_bias=self.d_use_bias, opt=opt,
+                                               scope=scope + "_2")
+                    else:
+                        x = resblock_down(x, channels=ch, use_bias=self.d_use_bias, opt=opt, scope=scope)
                 b_i += 1
                 if b_i == block_info["sa_index"]:
                     x = self_attention_2(x, channels=ch, opt=opt, scope='self_attention')

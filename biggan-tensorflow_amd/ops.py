@@ -359,12 +359,83 @@ def resblock_down(x_init, channels, opt, use_bias=True, scope='resblock_down'):
     return _add(x, x_init)
 
 
-def resblock_up_cond_deep(*a, **k):
-    raise NotImplementedError("--deep blocks (ops.py:317) are outside the default hot path")
+def _channel_slice(x, lo, hi):
+    """tf.split along channels: a contiguous copy of x[..., lo:hi] (data movement only)."""
+    if _is_meta(x):
+        return _meta(tuple(x.shape[:-1]) + (hi - lo,))
+    return x[..., lo:hi]
 
 
-def resblock_down_deep(*a, **k):
-    raise NotImplementedError("--deep blocks (ops.py:360) are outside the default hot path")
+def _channel_concat(a, b):
+    if _is_meta(a):
+        return _meta(tuple(a.shape[:-1]) + (a.shape[-1] + b.shape[-1],))
+    return torch.cat([a, b], dim=-1)
+
+
+def resblock_up_cond_deep(x_init, z, channels_out, opt, upscale=True, use_bias=True, scope='deep_resblock'):
+    """ops.py:317-358 (--deep): bottleneck 1x1 -> (upconv) -> two g_convs at (Cin + Cout) // 6 channels -> 1x1."""
+    channels_in = int(x_init.shape[-1])
+    inner_channels = round_up((channels_in + channels_out) // 6, 8)
+    with variable_scope(scope):
+        x_main, x_skip = _fork(x_init)
+        with variable_scope('bottleneck'):
+            x = _bn_act(x_main, z, opt)
+            x = conv(x, inner_channels, kernel=1, stride=1, use_bias=False, opt=opt)
+        with variable_scope('upscale'):
+            x = _bn_act(x, z, opt)
+            if upscale:
+                x = upconv(x, inner_channels, use_bias=False, opt=opt)
+        with variable_scope('inner1'):
+            x = g_conv(x, inner_channels, use_bias=False, opt=opt)
+            x = _bn_act(x, z, opt)
+        with variable_scope('inner2'):
+            x = g_conv(x, inner_channels, use_bias=False, opt=opt)
+            x = _bn_act(x, None, opt)
+        with variable_scope('proj'):
+            x = conv(x, channels_out, kernel=1, stride=1, use_bias=use_bias, opt=opt)
+        with variable_scope('skip'):
+            if upscale:
+                kept = _channel_slice(x_skip, 0, channels_out) if channels_in != channels_out else x_skip
+                x_skip = upconv(kept, channels_out, use_bias=use_bias, opt=opt)
+    return _add(x, x_skip)
+
+
+def resblock_down_deep(x_init, channels_out, opt, downscale=True, use_bias=True, scope='deep_resblock'):
+    """ops.py:360-401 (--deep)."""
+    channels_in = int(x_init.shape[-1])
+    inner_channels = round_up((channels_in + channels_out) // 6, 8)
+    with variable_scope(scope):
+        x_main, x_skip = _fork(x_init)
+        with variable_scope('bottleneck'):
+            x = x_main
+            if opt["bn_in_d"]:
+                x = bn(x, opt=opt)
+            x = opt["act"](x)
+            x = conv(x, inner_channels, kernel=1, stride=1, pad=0, use_bias=use_bias, opt=opt)
+        with variable_scope('inner1'):
+            if opt["bn_in_d"]:
+                x = bn(x, opt=opt)
+            x = opt["act"](x)
+            x = conv(x, inner_channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
+        with variable_scope('inner2'):
+            if opt["bn_in_d"]:
+                x = bn(x, opt=opt)
+            x = opt["act"](x)
+            x = conv(x, inner_channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
+        with variable_scope('downscale'):
+            x = opt["act"](x)
+            if downscale:
+                x = downconv(x, inner_channels, use_bias=use_bias, opt=opt, method='pool_only')
+        with variable_scope('proj'):
+            x = conv(x, channels_out, kernel=1, stride=1, pad=0, use_bias=use_bias, opt=opt)
+        with variable_scope('skip'):
+            if downscale:
+                x_skip = downconv(x_skip, channels_in, use_bias=use_bias, opt=opt, method='pool_only')
+            if channels_in != channels_out:
+                conv_ch = channels_out - channels_in
+                dense = conv(x_skip, conv_ch, kernel=1, stride=1, pad=0, use_bias=use_bias, opt=opt)
+                x_skip = _channel_concat(x_skip, dense)
+    return _add(x, x_skip)
 
 
 def clown_conv(*a, **k):

@@ -34,6 +34,7 @@ class Config:
         self.activation = "prelu"             # main.py:63
         self.upsampling_method = "deconv4"    # main.py:52
         self.g_conv = "deconv3"               # main.py:54
+        self.deep = False                     # main.py (--deep)
         self.downsampling_method = "strided_conv3"   # main.py:53
         self.bn_in_d = False                  # main.py:40
         self.g_grow_factor = 2.0
@@ -147,8 +148,12 @@ def generator(vs, cfg, z, cls_z=None, is_training=True):
             zi = next(nxt)
             if block_count > 1:
                 scope = scope + "_" + str(sb_i)                             # cumulative (BigGAN.py:455)
-            x = R.resblock_up_condition(vs, G + "/" + scope, x, z_split[zi], ch, opt,
-                                        use_bias=False, is_training=is_training)
+            if cfg.deep:                                                    # BigGAN.py:475-477
+                x = R.resblock_up_cond_deep(vs, G + "/" + scope, x, z_split[zi], ch, opt, True, True, is_training)
+                x = R.resblock_up_cond_deep(vs, G + "/" + scope + "_2", x, z_split[zi], ch, opt, False, True, is_training)
+            else:
+                x = R.resblock_up_condition(vs, G + "/" + scope, x, z_split[zi], ch, opt,
+                                            use_bias=False, is_training=is_training)
         b_i += 1
         if b_i == info["sa_index"]:
             x = R.self_attention_2(vs, G + "/self_attention", x, ch, opt)
@@ -174,7 +179,11 @@ def discriminator(vs, cfg, x):
         for sb_i in range(block_count):
             if block_count > 1:
                 scope = scope + "_" + str(sb_i)
-            x = R.resblock_down(vs, D + "/" + scope, x, ch, opt, use_bias=cfg.bias_in_d)
+            if cfg.deep:                                                    # BigGAN.py:629-631
+                x = R.resblock_down_deep(vs, D + "/" + scope, x, ch, opt, True, cfg.bias_in_d)
+                x = R.resblock_down_deep(vs, D + "/" + scope + "_2", x, ch, opt, False, cfg.bias_in_d)
+            else:
+                x = R.resblock_down(vs, D + "/" + scope, x, ch, opt, use_bias=cfg.bias_in_d)
         b_i += 1
         if b_i == info["sa_index"]:
             x = R.self_attention_2(vs, D + "/self_attention", x, ch, opt)

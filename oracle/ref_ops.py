@@ -409,6 +409,55 @@ def resblock_up_condition(vs, scope, x_init, z, channels, opt, use_bias=True, is
     return x + skip
 
 
+def resblock_up_cond_deep(vs, scope, x_init, z, channels_out, opt, upscale=True, use_bias=True, is_training=True):
+    """ops.py:317-358 (--deep)."""
+    cin = x_init.shape[-1]
+    inner = round_up((cin + channels_out) // 6, 8)
+    x = condition_batch_norm(vs, scope + "/bottleneck/batch_norm", x_init, z, opt, is_training)
+    x = activation(vs, scope + "/bottleneck/prelu", x, opt)
+    x = conv(vs, scope + "/bottleneck/conv_0", x, inner, opt, kernel=1, stride=1, pad=0, use_bias=False)
+    x = condition_batch_norm(vs, scope + "/upscale/batch_norm", x, z, opt, is_training)
+    x = activation(vs, scope + "/upscale/prelu", x, opt)
+    if upscale:
+        x = upconv(vs, scope + "/upscale", x, inner, opt, use_bias=False)
+    x = g_conv(vs, scope + "/inner1", x, inner, opt, use_bias=False)
+    x = condition_batch_norm(vs, scope + "/inner1/batch_norm", x, z, opt, is_training)
+    x = activation(vs, scope + "/inner1/prelu", x, opt)
+    x = g_conv(vs, scope + "/inner2", x, inner, opt, use_bias=False)
+    x = batch_norm(vs, scope + "/inner2/batch_norm", x, opt, is_training)
+    x = activation(vs, scope + "/inner2/prelu", x, opt)
+    x = conv(vs, scope + "/proj/conv_0", x, channels_out, opt, kernel=1, stride=1, pad=0, use_bias=use_bias)
+    skip = x_init
+    if upscale:
+        kept = x_init[..., :channels_out] if cin != channels_out else x_init
+        skip = upconv(vs, scope + "/skip", kept, channels_out, opt, use_bias=use_bias)
+    return x + skip
+
+
+def resblock_down_deep(vs, scope, x_init, channels_out, opt, downscale=True, use_bias=True):
+    """ops.py:360-401 (--deep)."""
+    cin = x_init.shape[-1]
+    inner = round_up((cin + channels_out) // 6, 8)
+    x = x_init
+    for name, k, pad in (("bottleneck", 1, 0), ("inner1", 3, 1), ("inner2", 3, 1)):
+        if opt.get("bn_in_d"):
+            x = batch_norm(vs, scope + "/" + name + "/batch_norm", x, opt, True)
+        x = activation(vs, scope + "/" + name + "/prelu", x, opt)
+        x = conv(vs, scope + "/" + name + "/conv_0", x, inner, opt, kernel=k, stride=1, pad=pad, use_bias=use_bias)
+    x = activation(vs, scope + "/downscale/prelu", x, opt)
+    if downscale:
+        x = avg_pooling(x)
+    x = conv(vs, scope + "/proj/conv_0", x, channels_out, opt, kernel=1, stride=1, pad=0, use_bias=use_bias)
+    skip = x_init
+    if downscale:
+        skip = avg_pooling(skip)
+    if cin != channels_out:
+        dense = conv(vs, scope + "/skip/conv_0", skip, channels_out - cin, opt, kernel=1, stride=1, pad=0,
+                     use_bias=use_bias)
+        skip = torch.cat([skip, dense], dim=-1)
+    return x + skip
+
+
 def downconv(vs, scope, x, channels, opt, use_bias=True, method=None):
     """ops.py:269-291: strided_conv3 (default), resize_conv1 / resize_conv3 = conv k1 / k3 stride 1 + avg pool."""
     m = method or opt.get("downsampling_method", "strided_conv3")

@@ -349,6 +349,7 @@ def test_sample_with_ema_weights():
     (dict(downsampling_method="resize_conv3"), dict(downsampling_method="resize_conv3")),
     (dict(g_regularization="ortho"), dict()),
     (dict(g_regularization="l2"), dict()),
+    (dict(deep=True), dict(deep="true")),
 ])
 def test_step_parity_non_default_flags(okw, hkw):
     """--activation relu / lrelu (BigGAN.py:71-83), --conv_padding zero (TF SAME,
