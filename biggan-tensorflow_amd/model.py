@@ -20,7 +20,7 @@ from . import functional as Fn
 from . import scope as S
 from . import hip
 from .ops import (fully_connected, resblock_up_condition, resblock_down, resblock, self_attention_2, conv, bn,
-                  resblock_up_cond_deep, resblock_down_deep,
+                  resblock_up_cond_deep, resblock_down_deep, upconv, g_conv, cond_bn,
                   prelu, relu, lrelu, tanh, global_sum_pooling, discriminator_loss, generator_loss)
 from .DiffAugment import DiffAugment, draw as draw_augment
 from .utils import orthogonal_regularizer, orthogonal_regularizer_fc, l2_regularizer, round_up, cls_loss_fn
@@ -60,16 +60,14 @@ class BigGAN(GANBase):
         self.depth = args.img_size.bit_length() - 2                                   # BigGAN.py:19
 
         unsupported = [
-            ("cls_embedding", args.cls_embedding), ("d_cls_dense_layers", args.d_cls_dense_layers),
+            ("cls_embedding", args.cls_embedding),
             ("shared_z", args.shared_z > 0), ("g_z_dense_concat", args.g_z_dense_concat),
-            ("g_other_level_dense_layer", args.g_other_level_dense_layer),
-            ("g_no_last_resblock", args.g_no_last_resblock), ("g_mixed_resblocks", args.g_mixed_resblocks),
+            ("g_mixed_resblocks", args.g_mixed_resblocks),
             ("g_final_layer", args.g_final_layer), ("multi_head", args.multi_head),
             ("z_reconstruct", args.z_reconstruct), ("d_reconstruction", args.d_reconstruction),
             ("d_reconstruction_halfres", args.d_reconstruction_halfres),
             ("d_reconstruction_texture", args.d_reconstruction_texture), ("d_final_conv", args.d_final_conv),
             ("c_dim!=3", args.c_dim != 3),
-            ("not g_first_level_dense_layer", not args.g_first_level_dense_layer),
         ]
         bad = [n for n, v in unsupported if v]
         if bad:
@@ -271,7 +269,9 @@ class BigGAN(GANBase):
 
             layer_z, z_dim = next_z_split()
             f_width = self.round_up(z_dim * 1.85, 8)                                   # BigGAN.py:433 (z_dim includes the labels)
-            if self.activation_fn is relu:                                             # BigGAN.py:434-438
+            if not self.args.g_first_level_dense_layer:                                # BigGAN.py:444
+                x = fully_connected(layer_z, units=4 * 4 * ch, scope='dense', opt=opt)
+            elif self.activation_fn is relu:                                           # BigGAN.py:434-438
                 x = fully_connected(layer_z, units=f_width, scope='dense1', opt=opt)
                 x = relu(x)
                 x = fully_connected(x, units=4 * 4 * ch, scope='dense2', opt=opt)
@@ -289,7 +289,19 @@ class BigGAN(GANBase):
                     layer_z, z_dim = next_z_split()
                     if block_count > 1:
                         scope = scope + '_' + str(sb_i)                                # cumulative (BigGAN.py:455)
-                    if self.deep:                                                      # BigGAN.py:475-477
+                    if self.args.g_other_level_dense_layer:                            # BigGAN.py:457-462
+                        with S.variable_scope('z' + str(ch_mul)):
+                            zw = self.round_up(z_dim * 1.25, 8)                        # (z_dim includes the labels)
+                            layer_z = fully_connected(layer_z, units=zw, scope='dense1', opt=opt)
+                            layer_z = opt["act"](layer_z)
+                    is_last_block = sb_i == block_count - 1 and b_i == len(counts) - 1
+                    if self.args.g_no_last_resblock and is_last_block:                 # BigGAN.py:468-473
+                        with S.variable_scope(scope):
+                            x = upconv(x, ch, use_bias=False, opt=opt)
+                            x = cond_bn(x, layer_z, opt=opt)
+                            x = opt["act"](x)
+                            x = g_conv(x, ch, use_bias=False, opt=opt)
+                    elif self.deep:                                                    # BigGAN.py:475-477
                         x = resblock_up_cond_deep(x, layer_z, channels_out=ch, use_bias=True, opt=opt, scope=scope)
                         x = resblock_up_cond_deep(x, layer_z, channels_out=ch, upscale=False, use_bias=True, opt=opt,
                                                   scope=scope + "_2")
@@ -357,7 +369,18 @@ class BigGAN(GANBase):
             outputs["real"] = x
             if self.acgan:                                                             # BigGAN.py:686-701
                 cls_opt = self.make_opt_with_sn(opt, self.d_compat_use_sn_in_classification)
-                outputs["cls"] = fully_connected(features, units=self.n_labels, opt=cls_opt, scope='DC_logit')
+                if self.args.d_cls_dense_layers:                                       # BigGAN.py:690-698
+                    with S.variable_scope("classification"):
+                        u1 = self.round_up(ch / 16.0 + self.n_labels * 1.25, 8)
+                        y = fully_connected(features, units=u1, opt=cls_opt, scope='dense1')
+                        y = opt["act"](y)
+                        u2 = self.round_up(u1 / 4.0 + self.n_labels * 1.1, 4)
+                        y = fully_connected(y, units=u2, opt=cls_opt, scope='dense2')
+                        y = opt["act"](y)
+                        y = fully_connected(y, units=self.n_labels, opt=cls_opt, scope='DC_logit')
+                    outputs["cls"] = y
+                else:
+                    outputs["cls"] = fully_connected(features, units=self.n_labels, opt=cls_opt, scope='DC_logit')
             return outputs
 
     ##################################################################################

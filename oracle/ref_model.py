@@ -35,6 +35,10 @@ class Config:
         self.upsampling_method = "deconv4"    # main.py:52
         self.g_conv = "deconv3"               # main.py:54
         self.deep = False                     # main.py (--deep)
+        self.g_first_level_dense_layer = True # main.py:90
+        self.g_other_level_dense_layer = False
+        self.g_no_last_resblock = False
+        self.d_cls_dense_layers = False       # main.py:94
         self.downsampling_method = "strided_conv3"   # main.py:53
         self.bn_in_d = False                  # main.py:40
         self.g_grow_factor = 2.0
@@ -136,9 +140,12 @@ def generator(vs, cfg, z, cls_z=None, is_training=True):
     zi = next(nxt)
     f_width = R.round_up((sizes[zi] + cfg.n_labels) * 1.85, 8)               # BigGAN.py:433
     first = G if cfg.activation == "relu" else G + "/first"              # BigGAN.py:434-443: no scope with relu
-    x = R.fully_connected(vs, first + "/dense1", z_split[zi], f_width, opt)
-    x = R.activation(vs, first + "/prelu", x, opt)
-    x = R.fully_connected(vs, first + "/dense2", x, 4 * 4 * ch, opt)
+    if not cfg.g_first_level_dense_layer:                                   # BigGAN.py:444
+        x = R.fully_connected(vs, G + "/dense", z_split[zi], 4 * 4 * ch, opt)
+    else:
+        x = R.fully_connected(vs, first + "/dense1", z_split[zi], f_width, opt)
+        x = R.activation(vs, first + "/prelu", x, opt)
+        x = R.fully_connected(vs, first + "/dense2", x, 4 * 4 * ch, opt)
     x = x.reshape(-1, 4, 4, ch)                                             # BigGAN.py:446
 
     b_i = 0
@@ -148,11 +155,24 @@ def generator(vs, cfg, z, cls_z=None, is_training=True):
             zi = next(nxt)
             if block_count > 1:
                 scope = scope + "_" + str(sb_i)                             # cumulative (BigGAN.py:455)
-            if cfg.deep:                                                    # BigGAN.py:475-477
-                x = R.resblock_up_cond_deep(vs, G + "/" + scope, x, z_split[zi], ch, opt, True, True, is_training)
-                x = R.resblock_up_cond_deep(vs, G + "/" + scope + "_2", x, z_split[zi], ch, opt, False, True, is_training)
+            block_z = z_split[zi]
+            if cfg.g_other_level_dense_layer:                               # BigGAN.py:457-462
+                zs = G + "/z" + str(ch_mul)
+                zw = R.round_up((sizes[zi] + cfg.n_labels) * 1.25, 8)
+                block_z = R.activation(vs, zs + "/prelu", R.fully_connected(vs, zs + "/dense1", block_z, zw, opt), opt)
+                block_z = block_z.reshape(block_z.shape[0], 1, 1, -1)
+            is_last = sb_i == block_count - 1 and b_i == len(counts) - 1
+            if cfg.g_no_last_resblock and is_last:                          # BigGAN.py:468-473
+                sc = G + "/" + scope
+                x = R.upconv(vs, sc, x, ch, opt, use_bias=False)
+                x = R.condition_batch_norm(vs, sc + "/batch_norm", x, block_z, opt, is_training)
+                x = R.activation(vs, sc + "/prelu", x, opt)
+                x = R.g_conv(vs, sc, x, ch, opt, use_bias=False)
+            elif cfg.deep:                                                  # BigGAN.py:475-477
+                x = R.resblock_up_cond_deep(vs, G + "/" + scope, x, block_z, ch, opt, True, True, is_training)
+                x = R.resblock_up_cond_deep(vs, G + "/" + scope + "_2", x, block_z, ch, opt, False, True, is_training)
             else:
-                x = R.resblock_up_condition(vs, G + "/" + scope, x, z_split[zi], ch, opt,
+                x = R.resblock_up_condition(vs, G + "/" + scope, x, block_z, ch, opt,
                                             use_bias=False, is_training=is_training)
         b_i += 1
         if b_i == info["sa_index"]:
@@ -197,8 +217,16 @@ def discriminator(vs, cfg, x):
     out["real"] = R.fully_connected(vs, D + "/D_logit", feat, 1, opt,
                                     sn=cfg.d_compat_use_sn_in_critic_output)   # :681-682, 1482-1487
     if cfg.n_labels > 0:                                                    # :689-701
-        out["cls"] = R.fully_connected(vs, D + "/DC_logit", feat, cfg.n_labels, opt,
-                                       sn=cfg.d_compat_use_sn_in_classification)
+        csn = cfg.d_compat_use_sn_in_classification
+        if cfg.d_cls_dense_layers:                                          # :690-698
+            C = D + "/classification"
+            u1 = R.round_up(ch / 16.0 + cfg.n_labels * 1.25, 8)
+            y = R.activation(vs, C + "/prelu", R.fully_connected(vs, C + "/dense1", feat, u1, opt, sn=csn), opt)
+            u2 = R.round_up(u1 / 4.0 + cfg.n_labels * 1.1, 4)
+            y = R.activation(vs, C + "/prelu_1", R.fully_connected(vs, C + "/dense2", y, u2, opt, sn=csn), opt)
+            out["cls"] = R.fully_connected(vs, C + "/DC_logit", y, cfg.n_labels, opt, sn=csn)
+        else:
+            out["cls"] = R.fully_connected(vs, D + "/DC_logit", feat, cfg.n_labels, opt, sn=csn)
     return out
 
 

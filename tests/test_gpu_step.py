@@ -350,6 +350,13 @@ def test_sample_with_ema_weights():
     (dict(g_regularization="ortho"), dict()),
     (dict(g_regularization="l2"), dict()),
     (dict(deep=True), dict(deep="true")),
+    (dict(g_first_level_dense_layer=False), dict(g_first_level_dense_layer="false")),
+    (dict(g_other_level_dense_layer=True), dict(g_other_level_dense_layer="true")),
+    # (with the default deconv up-sampling AND deconv g_conv the last block would create two 'deconv_0/kernel'
+    #  variables in one scope - an error in the reference too; resize_conv gives them distinct scopes)
+    (dict(g_no_last_resblock=True, upsampling_method="resize_conv"),
+     dict(g_no_last_resblock="true", upsampling_method="resize_conv")),
+    (dict(n_labels=6, d_cls_dense_layers=True), dict(n_labels=6, d_cls_dense_layers="true")),
 ])
 def test_step_parity_non_default_flags(okw, hkw):
     """--activation relu / lrelu (BigGAN.py:71-83), --conv_padding zero (TF SAME,

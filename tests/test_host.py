@@ -156,7 +156,7 @@ def test_sample_grid_png(tmp_path):
 
 def test_out_of_scope_flags_rejected_at_build():
     for extra in (["--g_final_layer", "true"], ["--cls_embedding", "true"], ["--gan_type", "ra-dragan"], ["--g_final_layer", "true"],
-                  ["--bn_type", "batch_renorm"], ["--d_cls_dense_layers", "true"]):
+                  ["--bn_type", "batch_renorm"], ["--z_reconstruct", "true"]):
         argv = ["--gan_type", "hinge", "--img_size", "64"] + extra
         with pytest.raises(NotImplementedError):
             model.BigGAN(M.parse_args(argv, make_dirs=False), device="cpu", store=S.VariableStore("cpu"))
