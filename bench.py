@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--da_policy", type=str, default="full")
     ap.add_argument("--g_regularization", type=str, default="ortho_cosine")
     ap.add_argument("--n_labels", type=int, default=0, help="class-conditional variant: synthetic one-hot labels")
+    ap.add_argument("--graph", action="store_true", help="replay the iteration from captured HIP graphs (N=1 only)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     a = ap.parse_args()
@@ -199,7 +200,12 @@ def main():
         if rank == 0:
             print("[bench %7.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
-    note("model built: %s" % desc)
+    if a.graph:
+        if world != 1:
+            raise SystemExit("--graph is a single-process option")
+        gan.capture_graphs(B)
+        a.no_roofline = True            # per-launch HIP events cannot be recorded inside a replayed graph
+    note("model built: %s%s" % (desc, " (HIP-graph replay)" if a.graph else ""))
     for i in range(a.warmup):
         gan.train_step(real)
         torch.cuda.synchronize()
@@ -259,7 +265,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": desc, "img_size": img, "ch": ch, "per_gpu_batch": B, "global_batch": B * world,
-                       "da_policy": a.da_policy, "g_regularization": a.g_regularization, "n_labels": a.n_labels,
+                       "da_policy": a.da_policy, "g_regularization": a.g_regularization, "n_labels": a.n_labels, "hip_graph": bool(a.graph),
                        "parallelism": "dp%d" % world},
             "losses": {k: round(float(v.item()), 5) for k, v in losses.items()},
         }

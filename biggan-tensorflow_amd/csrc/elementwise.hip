@@ -944,8 +944,10 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_batch_bwd_kernel(const BgSnItem* 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(EW_BLOCK) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v,
-                                                         float* __restrict__ ema, float lr_t, float b1, float b2,
+                                                         float* __restrict__ ema, float lr_arg, const float* __restrict__ lr_dev,
+                                                         float b1, float b2,
                                                          float eps, float decay, float gscale, int64_t n) {
+    const float lr_t = lr_dev ? *lr_dev : lr_arg;      // device scalar: the launch can be replayed from a HIP graph
     for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -1361,8 +1363,17 @@ int bg_spectral_norm_batch_bwd(const BgSnItem* items_dev, int n_items, const uin
 int bg_adam_tf_ema_step(float* p, const float* g, float* m, float* v, float* ema, float lr_t, float b1, float b2,
                         float eps, float ema_decay, float grad_scale, int64_t n, void* stream) {
     BG_REQUIRE(p && g && m && v && n > 0, "bg_adam_tf_ema_step: bad argument");
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, as_stream(stream), p, g, m, v, ema, lr_t, b1,
-                       b2, eps, ema_decay, grad_scale, n);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, as_stream(stream), p, g, m, v, ema, lr_t,
+                       (const float*)nullptr, b1, b2, eps, ema_decay, grad_scale, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_adam_tf_ema_step_dev(float* p, const float* g, float* m, float* v, float* ema, const float* lr_t_dev, float b1,
+                            float b2, float eps, float ema_decay, float grad_scale, int64_t n, void* stream) {
+    BG_REQUIRE(p && g && m && v && lr_t_dev && n > 0, "bg_adam_tf_ema_step_dev: bad argument");
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, as_stream(stream), p, g, m, v, ema, 0.f,
+                       lr_t_dev, b1, b2, eps, ema_decay, grad_scale, n);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -118,6 +118,8 @@ SIGNATURES = {
     "bg_ortho_lowrank_finish": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     "bg_adam_tf_ema_step": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_float,
                                     c_int64, _P]),
+    "bg_adam_tf_ema_step_dev": (c_int, [_P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int64,
+                                        _P]),
     "bg_prof_enable": (None, [c_int]),
     "bg_prof_reset": (None, []),
     "bg_prof_collect": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),

@@ -461,15 +461,23 @@ class BigGAN(GANBase):
             from .parallel import allreduce_flat
             allreduce_flat(arena.grads, self.pg)
 
-    def _adam(self, arena, lr, with_ema, grad_scale=1.0):
+    def _adam_prepare(self, arena, lr):
+        """Host part of an optimiser step: advance the step count and put the bias-corrected step size
+        lr * sqrt(1 - beta2^t) / (1 - beta1^t) (tf.train.AdamOptimizer) into the arena's device scalar."""
         arena.step += 1
         t = arena.step
-        lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)        # tf.train.AdamOptimizer
-        hip.check(hip.lib().bg_adam_tf_ema_step(
+        lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        if getattr(arena, "lr_dev", None) is None:
+            arena.lr_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+        arena.lr_dev.fill_(lr_t)
+
+    def _adam(self, arena, lr, with_ema, grad_scale=1.0):
+        if not getattr(self, "_capturing", False):
+            self._adam_prepare(arena, lr)          # (a captured graph is replayed after _adam_prepare on the host)
+        hip.check(hip.lib().bg_adam_tf_ema_step_dev(
             hip.f32(arena.params), hip.f32(arena.grads), hip.f32(arena.m), hip.f32(arena.v),
-            hip.f32(arena.ema) if with_ema else None, lr_t, self.beta1, self.beta2, 1e-8, self.moving_decay,
-            float(grad_scale),
-            arena.size, hip.stream()))
+            hip.f32(arena.ema) if with_ema else None, hip.f32(arena.lr_dev), self.beta1, self.beta2, 1e-8,
+            self.moving_decay, float(grad_scale), arena.size, hip.stream()))
 
     def sample_z(self, B):
         z = torch.empty(B, 1, 1, self.z_dim, dtype=torch.float32, device=self.device)
@@ -658,7 +666,14 @@ class BigGAN(GANBase):
 
     def train_step(self, real, labels=None):
         """One iteration of BigGAN.py:1061-1084.  ``real`` (and ``labels`` when n_labels > 0) may be lists
-        of --virtual_batches tensors."""
+        of --virtual_batches tensors.  After ``capture_graphs()`` the iteration is replayed from HIP graphs."""
+        if getattr(self, "_graphs_ready", False):
+            if self.acgan and labels is None:
+                labels = self.synthetic_labels(real.shape[0])
+            return self._train_step_graph(real, labels)
+        return self._train_step_eager(real, labels)
+
+    def _train_step_eager(self, real, labels=None):
         losses = {}
         first = real[0] if isinstance(real, (list, tuple)) else real
         if self.acgan and labels is None:
@@ -671,6 +686,74 @@ class BigGAN(GANBase):
             g = self.g_step(first.shape[0], after_generator=self._finish_d, real=real if self.relativistic else None)
             losses["g_loss"] = g["g_loss"]
         self._finish_d()
+        self.counter += 1
+        return losses
+
+    # ---- HIP-graph replay of the iteration (launch-bound configurations) -------------------------
+    def capture_graphs(self, B=None):
+        """Capture the D op and the G op (forward, backward, spectral-norm batches, optimiser) into two HIP
+        graphs (torch.cuda.CUDAGraph) with static input buffers.  ``train_step`` then copies the batch in,
+        refreshes the two Adam step sizes on the host and replays: ~4000 kernel launches per iteration cost
+        two graph launches, which is what bounds small configurations (BASELINE config 1 spends 6 ms of a
+        16 ms step in kernels).  Single process only (collectives are not captured)."""
+        if self.world != 1:
+            raise NotImplementedError("graph capture is for single-process runs")
+        if self.virtual_batches != 1:
+            raise NotImplementedError("graph capture with --virtual_batches > 1")
+        B = B or self.batch_size
+        self._g_real = torch.zeros(B, self.img_size, self.img_size, self.c_dim, dtype=torch.float32, device=self.device)
+        self._g_labels = (torch.zeros(B, self.n_labels, dtype=torch.float32, device=self.device) if self.acgan else None)
+        if getattr(self.d_arena, "lr_dev", None) is None:
+            for arena in (self.d_arena, self.g_arena):
+                arena.lr_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # untimed eager warm-up on a side stream (allocator pools, lazy initialisation), state restored afterwards
+        snap = self.state_tensors()
+        saved = {k: v.detach().clone() for k, v in snap.items()}
+        steps = (self.counter, self.d_arena.step, self.g_arena.step)
+        rng = self.gen.get_state()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._train_step_eager(self._g_real, self._g_labels)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+        def restore():
+            with torch.no_grad():
+                for k, v in snap.items():
+                    v.copy_(saved[k])
+            self.counter, self.d_arena.step, self.g_arena.step = steps
+            self.gen.set_state(rng)
+        restore()
+        self._capturing = True
+        try:
+            self._graph_d = torch.cuda.CUDAGraph()
+            self._graph_d.register_generator_state(self.gen)
+            with torch.cuda.graph(self._graph_d):
+                self._g_out_d = self.d_step(self._g_real, labels=self._g_labels)
+            self._graph_g = torch.cuda.CUDAGraph()
+            self._graph_g.register_generator_state(self.gen)
+            with torch.cuda.graph(self._graph_g, pool=self._graph_d.pool()):
+                self._g_out_g = self.g_step(B, real=self._g_real if self.relativistic else None)
+        finally:
+            self._capturing = False
+        torch.cuda.synchronize()
+        restore()                      # capture does not execute kernels, but it advanced host-side bookkeeping
+        self._graphs_ready = True
+        return self
+
+    def _train_step_graph(self, real, labels):
+        self._g_real.copy_(real)
+        if self._g_labels is not None:
+            self._g_labels.copy_(labels)
+        losses = {}
+        self._adam_prepare(self.d_arena, self.d_learning_rate)
+        self._graph_d.replay()
+        losses["d_loss"] = self._g_out_d["d_loss"]
+        if (self.counter - 1) % self.n_critic == 0:
+            self._adam_prepare(self.g_arena, self.g_learning_rate)
+            self._graph_g.replay()
+            losses["g_loss"] = self._g_out_g["g_loss"]
         self.counter += 1
         return losses
 

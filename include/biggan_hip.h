@@ -320,6 +320,11 @@ int bg_ortho_lowrank_finish(float* dW, const float* P, const float* s, const flo
 int bg_adam_tf_ema_step(float* p, const float* g, float* m, float* v, float* ema,
                         float lr_t, float b1, float b2, float eps, float ema_decay, float grad_scale,
                         int64_t n, void* stream);
+/* Same update with the bias-corrected step size read from device memory (lr_t_dev[0]): the launch carries no
+ * per-step host scalar, so a captured HIP graph of the training step can be replayed. */
+int bg_adam_tf_ema_step_dev(float* p, const float* g, float* m, float* v, float* ema, const float* lr_t_dev,
+                            float b1, float b2, float eps, float ema_decay, float grad_scale, int64_t n,
+                            void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Optional per-kernel timing for bench.py's roofline leg: when enabled, every MFMA GEMM launch

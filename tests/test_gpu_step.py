@@ -448,6 +448,54 @@ def test_train_on_a_png_folder(tmp_path):
     assert gan.counter == 2
 
 
+def test_hip_graph_replay_matches_eager_iterations():
+    """BigGAN.capture_graphs(): the D op and the G op replayed from HIP graphs follow the eager iterations exactly
+    (same RNG stream, same Adam step sizes through the device scalar) for three iterations.  One model instance
+    (the ops resolve variables through a process-wide default store, like one TF graph): eager iterations from a
+    saved state, then capture, rewind and replay."""
+    from tests.common import make_args
+    from biggan_tensorflow_amd import model, scope as S
+    gan = model.BigGAN(make_args(img_size=64, ch=8, batch_size=4, z_dim=64),
+                       store=S.VariableStore("cuda", seed=5)).build_model()
+    reals = [gan.synthetic_batch(4) for _ in range(3)]
+    snap = gan.state_tensors()
+    saved = {k: v.detach().clone() for k, v in snap.items()}
+    rng = gan.gen.get_state()
+
+    def rewind():
+        with torch.no_grad():
+            for k, v in snap.items():
+                v.copy_(saved[k])
+        gan.counter, gan.d_arena.step, gan.g_arena.step = 0, 0, 0
+        gan.gen.set_state(rng)
+    eager_losses = []
+    for real in reals:
+        l = gan.train_step(real)
+        eager_losses.append((l["d_loss"].item(), l["g_loss"].item()))
+    eager_state = {k: v.detach().clone() for k, v in snap.items()}
+    rewind()
+    gan.capture_graphs()
+    assert gan._graphs_ready and gan.counter == 0 and gan.d_arena.step == 0
+    for k, v in snap.items():
+        assert torch.equal(v, saved[k]), ("capture must leave the state untouched", k)
+    gan.gen.set_state(rng)
+    for real, (de, ge) in zip(reals, eager_losses):
+        l = gan.train_step(real)
+        assert abs(l["d_loss"].item() - de) <= 1e-5 * abs(de) and abs(l["g_loss"].item() - ge) <= 1e-5 * abs(ge)
+    assert gan.counter == 3 and gan.d_arena.step == 3 and gan.g_arena.step == 3
+    # weights: identical up to the Adam(beta1 = 0) sign noise of ~zero gradient elements (|step| <= lr per iteration)
+    for k in gan.store.trainable_variables():
+        lr = gan.g_learning_rate if k.startswith("generator") else gan.d_learning_rate
+        diff = (snap[k] - eager_state[k]).abs()
+        assert float(diff.max()) <= 2.0 * 3 * lr * 1.01, (k, float(diff.max()))
+        if eager_state[k].numel() >= 64 and not _noise_driven(k):
+            rel = float(diff.double().norm() / eager_state[k].double().norm().clamp_min(1e-30))
+            assert rel < 5e-3, (k, rel)
+    for k in snap:
+        if k.endswith("/u"):
+            assert torch.allclose(snap[k], eager_state[k], atol=1e-5), k
+
+
 def test_train_loop_runs_and_loss_is_finite():
     from tests.common import make_args
     from biggan_tensorflow_amd import model, scope as S
