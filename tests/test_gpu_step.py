@@ -379,6 +379,16 @@ def test_step_parity_other_gan_losses(gan_type):
     _run_parity(tr, gan, batch)
 
 
+def test_step_parity_ch48_non_power_of_two_channels():
+    """--ch 48 (the channel arithmetic of BASELINE configs 3-5, ch = 96): 48 / 96 / 192 / 384 / 768 channels give
+    ragged GEMM tiles, the generator's attention (d = 12, dv = 48) runs through the fused kernels' zero-padded
+    operand tiles and the discriminator's (d = 6) through the materialised form."""
+    tr = oracle_trainer(64, 48, 128, 2)
+    gan = hip_model_like(tr)
+    batch = RM.synthetic_batch(tr.cfg, 23, 2)
+    _run_parity(tr, gan, batch, check_state=False)
+
+
 def test_extension_32px():
     tr = oracle_trainer(32, 16, 64, 4, extension_32=True)
     gan = hip_model_like(tr)
