@@ -435,6 +435,7 @@ class BigGAN(GANBase):
         return owner
 
     def _begin_run(self):
+        S.set_default_store(self.store)       # several models may live in one process: ops resolve variables here
         ops.begin_run(self._reduce_fn(), self.world, self.rank, getattr(self, "reg_owner", None))
 
     def _sn_prefetch(self, group, x):
@@ -854,6 +855,7 @@ class BigGAN(GANBase):
             live = arena.params.clone()
             arena.params.copy_(arena.ema)
         try:
+            S.set_default_store(self.store)
             ops.begin_run(None, 1)
             with torch.no_grad():
                 img = self.generator(z, cls_z, is_training=False, reuse=True)

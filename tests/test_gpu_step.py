@@ -506,6 +506,21 @@ def test_hip_graph_replay_matches_eager_iterations():
             assert torch.allclose(snap[k], eager_state[k], atol=1e-5), k
 
 
+def test_two_models_in_one_process_do_not_share_variables():
+    """The ops resolve variables through a process-wide default store (one TF graph in the reference); every
+    run re-binds it to the model that is stepping, so two models can be trained side by side."""
+    from tests.common import make_args
+    from biggan_tensorflow_amd import model, scope as S
+    a = model.BigGAN(make_args(img_size=64, ch=8, batch_size=2, z_dim=64), store=S.VariableStore("cuda", seed=1)).build_model()
+    b = model.BigGAN(make_args(img_size=64, ch=8, batch_size=2, z_dim=64), store=S.VariableStore("cuda", seed=2)).build_model()
+    b0 = b.g_arena.params.clone()
+    a0 = a.g_arena.params.clone()
+    a.train_step(a.synthetic_batch(2))              # b was built last: a must still step its OWN variables
+    assert torch.equal(b.g_arena.params, b0) and not torch.equal(a.g_arena.params, a0)
+    b.train_step(b.synthetic_batch(2))
+    assert not torch.equal(b.g_arena.params, b0)
+
+
 def test_train_loop_runs_and_loss_is_finite():
     from tests.common import make_args
     from biggan_tensorflow_amd import model, scope as S
