@@ -596,11 +596,20 @@ struct NNPlan {
 };
 
 // tile: the largest that still fills the 256 CUs; split K when even the smallest cannot
+// Stride phases with unequal tap counts (k3 s2: 1, 2, 2, 4 taps): a block of the heaviest phase runs 4x longer
+// than one of the lightest, so the grid needs more (smaller) blocks to keep 256 CUs busy until the end.
+static thread_local int g_plan_uneven = 0;
+struct UnevenPhases {
+    explicit UnevenPhases(const BgConvDesc* d) { g_plan_uneven = (d && d->stride > 1 && d->k % d->stride != 0) ? 1 : 0; }
+    ~UnevenPhases() { g_plan_uneven = 0; }
+};
+
 static NNPlan plan_nn(int64_t M, int N, int zdim, int niter_min, bool allow_split) {
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * zdim; };
     NNPlan pl;
     pl.splitk = 1;
-    const int64_t want = 384;
+    static const int want_uneven = getenv("BG_WANT_UNEVEN") ? atoi(getenv("BG_WANT_UNEVEN")) : 768;   // measured: 512->1024 8x8 dgrad 50 -> 79 TF/s
+    const int64_t want = g_plan_uneven ? want_uneven : 384;
     // narrow outputs with a long K and a handful of tiles (low-rank Gram of the cond-BN kernels: 32 x 32 x 1024
     // in ONE block = 64 serial K-steps = 44 us): split K
     auto narrow_split = [&](int bm, int bn) {
@@ -966,6 +975,7 @@ int bg_conv2d_fwd(const BgConvDesc* d, const float* x, const float* w, const flo
 
 size_t bg_conv2d_dgrad_workspace_bytes(const BgConvDesc* d) {
     if (!d) return 0;
+    UnevenPhases uneven(d);
     const int z = d->stride * d->stride;
     return nn_workspace_bytes((int64_t)d->N * (d->H / d->stride) * (d->W / d->stride), d->Cin, z,
                               tconv_min_iters(d, d->Cout), (int64_t)d->N * d->H * d->W * d->Cin);
@@ -977,6 +987,7 @@ int bg_conv2d_dgrad(const BgConvDesc* d, const float* dy, const float* w, const 
     if (rc) return rc;
     BG_REQUIRE(dy && w && dx, "bg_conv2d_dgrad: null tensor pointer");
     BG_REQUIRE(d->H % d->stride == 0 && d->W % d->stride == 0, "conv dgrad: H,W must be multiples of stride");
+    UnevenPhases uneven(d);
     NNParams p;
     conv_dgrad_params(d, p);
     p.A = dy; p.B = w; p.alpha = alpha_dev; p.out = dx; p.accumulate = accumulate;
