@@ -609,7 +609,8 @@ static NNPlan plan_nn(int64_t M, int N, int zdim, int niter_min, bool allow_spli
     NNPlan pl;
     pl.splitk = 1;
     static const int want_uneven = getenv("BG_WANT_UNEVEN") ? atoi(getenv("BG_WANT_UNEVEN")) : 768;   // measured: 512->1024 8x8 dgrad 50 -> 79 TF/s
-    const int64_t want = g_plan_uneven ? want_uneven : 384;
+    static const int want_even = getenv("BG_WANT") ? atoi(getenv("BG_WANT")) : 768;      // 3 blocks per CU (sweep: profiles/README)
+    const int64_t want = g_plan_uneven ? want_uneven : want_even;
     // narrow outputs with a long K and a handful of tiles (low-rank Gram of the cond-BN kernels: 32 x 32 x 1024
     // in ONE block = 64 serial K-steps = 44 us): split K
     auto narrow_split = [&](int bm, int bn) {
