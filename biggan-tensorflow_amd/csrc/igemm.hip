@@ -745,7 +745,8 @@ static TNPlan plan_tn(int Mf, int Cb, int batch, int M) {
     else if (Mf <= 64) { pl.bm = 64; pl.bn = 64; }
     else { pl.bm = 128; pl.bn = 128; }
     const int64_t tiles = (int64_t)((Mf + pl.bm - 1) / pl.bm) * ((Cb + pl.bn - 1) / pl.bn) * batch;
-    int64_t want = 768;
+    static const int tn_want = getenv("BG_TN_WANT") ? atoi(getenv("BG_TN_WANT")) : 2048;    // sweep 512..3072: best at 2048 (8 blocks per CU)
+    int64_t want = tn_want;
     int sk = (int)((want + tiles - 1) / tiles);
     const int max_sk = (M + 8 * BKT - 1) / (8 * BKT);      // at least 128 rows per split
     if (sk > max_sk) sk = max_sk;
