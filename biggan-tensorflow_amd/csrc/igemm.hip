@@ -637,7 +637,8 @@ static NNPlan plan_nn(int64_t M, int N, int zdim, int niter_min, bool allow_spli
         // efficient 128x128 tile and split K over blockIdx.z instead of shrinking the tile
         pl.bm = 128; pl.bn = 128;
         const int64_t b = blocks(128, 128);
-        int sk = (int)((768 + b - 1) / b);
+        static const int sk_target = getenv("BG_NN_SPLIT") ? atoi(getenv("BG_NN_SPLIT")) : 768;
+        int sk = (int)((sk_target + b - 1) / b);
         if (sk > niter_min / 8) sk = niter_min / 8;
         if (sk > 32) sk = 32;
         if (sk < 1) sk = 1;
