@@ -323,8 +323,17 @@ __global__ __launch_bounds__(256) void nn_slab_reduce_kernel(const float* __rest
                                                              int accumulate) {
     const float alpha = alpha_p ? *alpha_p : 1.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float s = 0.f;
-        for (int z = 0; z < splitk; ++z) s += ws[(int64_t)z * slab + i];
+        // 4 slabs in flight per thread (scalar path: outputs with N % 4 != 0 are rare and small)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int z = 0;
+        for (; z + 3 < splitk; z += 4) {
+            s0 += ws[(int64_t)z * slab + i];
+            s1 += ws[(int64_t)(z + 1) * slab + i];
+            s2 += ws[(int64_t)(z + 2) * slab + i];
+            s3 += ws[(int64_t)(z + 3) * slab + i];
+        }
+        for (; z < splitk; ++z) s0 += ws[(int64_t)z * slab + i];
+        float s = (s0 + s1) + (s2 + s3);
         s *= alpha;
         if (bias) s += bias[i % N];
         if (accumulate) s += out[i];
@@ -527,8 +536,20 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
                                                           int64_t n, int splitk, int64_t slab) {
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = 0; z < splitk; ++z) add4(s, ld4(ws + (int64_t)z * slab + i * 4));
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), t1 = s, t2 = s, t3 = s;
+        int z = 0;
+        for (; z + 3 < splitk; z += 4) {                 // 4 slabs in flight per thread
+            const float4 a = ld4(ws + (int64_t)z * slab + i * 4), b = ld4(ws + (int64_t)(z + 1) * slab + i * 4);
+            const float4 c = ld4(ws + (int64_t)(z + 2) * slab + i * 4), d = ld4(ws + (int64_t)(z + 3) * slab + i * 4);
+            add4(s, a);
+            add4(t1, b);
+            add4(t2, c);
+            add4(t3, d);
+        }
+        for (; z < splitk; ++z) add4(s, ld4(ws + (int64_t)z * slab + i * 4));
+        add4(s, t1);
+        add4(t2, t3);
+        add4(s, t2);
         *reinterpret_cast<float4*>(out + i * 4) = s;
     }
     for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
