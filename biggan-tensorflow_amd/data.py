@@ -29,6 +29,20 @@ def _paeth(a, b, c):
 
 
 def _unfilter(raw, h, stride, bpp):
+    try:                                                # C helper of libbiggan_hip.so (host code, no GPU involved)
+        from . import hip
+        out = np.empty((h, stride), np.uint8)
+        if len(raw) < h * (stride + 1):
+            raise ValueError("PNG: truncated image data")
+        rc = hip.lib().bg_png_unfilter(bytes(raw), h, stride, bpp, out.ctypes.data_as(hip.c_void_p))
+        if rc != 0:
+            raise ValueError("PNG: " + hip.lib().bg_last_error().decode())
+        return out
+    except ImportError:                                 # library not built: pure-Python fallback (slow)
+        return _unfilter_py(raw, h, stride, bpp)
+
+
+def _unfilter_py(raw, h, stride, bpp):
     out = np.zeros((h, stride), np.uint8)
     prev = np.zeros(stride, np.int32)
     pos = 0
@@ -138,6 +152,7 @@ class ImageData:
         self.custom_dataset = custom_dataset
         self.flip = flip
         self.rng = np.random.default_rng(seed)
+        self._lock = threading.Lock()                   # image_processing runs on the loader's decode threads
 
     def image_processing(self, filename):
         if not self.custom_dataset:
@@ -148,8 +163,11 @@ class ImageData:
             with open(filename, "rb") as f:
                 x_decode = decode_png(f.read(), channels=self.channels)
         img = resize_bilinear_legacy(x_decode, self.load_size)
-        if self.flip and self.rng.random() < 0.5:        # tf.image.random_flip_left_right
-            img = img[:, ::-1]
+        if self.flip:                                    # tf.image.random_flip_left_right
+            with self._lock:
+                flip = self.rng.random() < 0.5
+            if flip:
+                img = img[:, ::-1]
         return (img / 127.5 - 1).astype(np.float32)
 
     def image_processing_with_labels(self, filename, label):
@@ -197,13 +215,15 @@ class BatchLoader:
     decodes ahead (queue depth 4); ``rank`` / ``world`` give each data-parallel rank a disjoint shard of
     every shuffled epoch."""
 
-    def __init__(self, files, labels, batch_size, image_data, device, seed=0, rank=0, world=1, depth=4):
+    def __init__(self, files, labels, batch_size, image_data, device, seed=0, rank=0, world=1, depth=4, workers=8):
         if len(files) < batch_size * world:
             raise ValueError("dataset has %d files, fewer than one global batch (%d)" % (len(files), batch_size * world))
         self.files, self.labels = list(files), labels
         self.batch_size, self.image_data, self.device = batch_size, image_data, torch.device(device)
         self.rank, self.world = rank, world
         self.rng = np.random.default_rng(seed)          # same seed on every rank: identical permutations
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=workers)     # zlib, the C unfilter and numpy release the GIL
         self.q = queue.Queue(maxsize=depth)
         self.stop = threading.Event()
         self.thread = threading.Thread(target=self._work, daemon=True)
@@ -216,7 +236,7 @@ class BatchLoader:
                 per_step = self.batch_size * self.world
                 for s in range(0, len(order) - per_step + 1, per_step):
                     idx = order[s + self.rank * self.batch_size: s + (self.rank + 1) * self.batch_size]
-                    imgs = np.stack([self.image_data.image_processing(self.files[i]) for i in idx])
+                    imgs = np.stack(list(self.pool.map(lambda i: self.image_data.image_processing(self.files[i]), idx)))
                     item = [torch.from_numpy(imgs)]
                     if self.labels is not None:
                         item.append(torch.tensor(np.asarray([self.labels[i] for i in idx], np.float32)))
@@ -251,3 +271,4 @@ class BatchLoader:
         except queue.Empty:
             pass
         self.thread.join(2)
+        self.pool.shutdown(wait=False)

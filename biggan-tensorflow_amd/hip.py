@@ -42,6 +42,7 @@ SIGNATURES = {
     "bg_abi_version": (c_int, []),
     "bg_last_error": (c_char_p, []),
     "bg_target_arch": (c_char_p, []),
+    "bg_png_unfilter": (c_int, [c_char_p, c_int, c_int, c_int, _P]),
     "bg_set_gemm_compute": (None, [c_int]),
     "bg_get_gemm_compute": (c_int, []),
     "bg_conv2d_fwd_workspace_bytes": (c_size_t, [_CD]),

@@ -35,6 +35,10 @@ const char* bg_last_error(void);
 /* "gfx950" - the only code object in the library */
 const char* bg_target_arch(void);
 
+/* Host-side helper of the input pipeline (utils.py:12-38 decode_png): reverse the PNG row filters of an 8-bit
+ * image on the CPU.  raw: h rows of 1 filter byte + stride bytes (the inflated IDAT stream); out: h * stride. */
+int bg_png_unfilter(const unsigned char* raw, int h, int stride, int bpp, unsigned char* out);
+
 /* --------------------------------------------------------------------------------------------
  * Convolution geometry shared by conv / transposed conv (ops.py:49-139).
  *   conv   : x[N,H,W,Cin]  -> y[N,Ho,Wo,Cout],  Ho = (H + pad_lo + pad_hi - k)/stride + 1
