@@ -158,6 +158,52 @@ __global__ void bn_finalize_kernel(const double* sums, double count, float eps, 
 }
 
 // ------------------------------------------------------------------------------------------
+// batch renormalisation: clipped corrections r, d against running statistics (ops.py:600-609, 645-715)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void renorm_coeffs_kernel(const double* __restrict__ sums, double count,
+                                                            float* ref_mean, float* ref_scale, int scale_is_var,
+                                                            float* weight, float eps, float rmin, float rmax, float dmax,
+                                                            float decay, float fade, int update, float* __restrict__ r,
+                                                            float* __restrict__ d, int C) {
+    const float w = weight ? *weight : 1.f;              // every thread reads the fade-in weight before it moves
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double m64 = sums[c] / count;
+        double v64 = sums[C + c] / count - m64 * m64;
+        if (v64 < 0) v64 = 0;
+        const float m = (float)m64, var = (float)v64;
+        const float sigma = sqrtf(var + eps);
+        const float rm = ref_mean[c], rs = ref_scale[c];
+        const float sigma_ref = scale_is_var ? sqrtf(rs + eps) : fmaxf(rs, sqrtf(eps));
+        const float sigma_w = w * sigma_ref + (1.f - w) * sigma;
+        const float mean_w = w * rm + (1.f - w) * m;
+        r[c] = fminf(fmaxf(sigma / sigma_w, rmin), rmax);
+        d[c] = fminf(fmaxf((m - mean_w) / sigma_w, -dmax), dmax);
+        if (update) {
+            ref_mean[c] = rm * decay + m * (1.f - decay);
+            ref_scale[c] = rs * decay + (scale_is_var ? var : sigma) * (1.f - decay);
+        }
+    }
+    if (update && weight && threadIdx.x == 0) *weight = w * fade + 1.0f * (1.f - fade);
+}
+
+// dir 0: a = r*gamma, b = beta + d*gamma ; dir 1: a = r*dgamma_eff + d*dbeta_eff (gradient of gamma)
+__global__ __launch_bounds__(EW_BLOCK) void renorm_affine_kernel(const float* __restrict__ g, const float* __restrict__ b,
+                                                                 const float* __restrict__ r, const float* __restrict__ d,
+                                                                 float* __restrict__ oa, float* __restrict__ ob,
+                                                                 int64_t total, int C, int dir) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        if (dir == 0) {
+            oa[i] = r[c] * g[i];
+            ob[i] = b[i] + d[c] * g[i];
+        } else {
+            oa[i] = r[c] * g[i] + d[c] * b[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // (conditional) batch-norm apply + PReLU
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float prelu_f(float v, float a) { return v > 0.f ? v : a * v; }
@@ -979,6 +1025,37 @@ int bg_bn_finalize(const double* sums, double count, float eps, float momentum, 
     BG_REQUIRE(sums && mean && rstd && C > 0 && count > 0, "bg_bn_finalize: bad argument");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count, eps,
                        momentum, unbiased_moving_var, mean, rstd, moving_mean, moving_var, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_renorm_coeffs(const double* sums, double count, float* ref_mean, float* ref_scale, int scale_is_var, float* weight,
+                     float eps, float rmin, float rmax, float dmax, float decay, float fadein_decay, int update, float* r,
+                     float* d, int C, void* stream) {
+    BG_REQUIRE(sums && ref_mean && ref_scale && r && d && C > 0 && count > 0, "bg_renorm_coeffs: bad argument");
+    BG_REQUIRE(rmin > 0 && rmax >= rmin && dmax >= 0, "bg_renorm_coeffs: bad clipping range");
+    hipLaunchKernelGGL(renorm_coeffs_kernel, dim3(1), dim3(256), 0, as_stream(stream), sums, count, ref_mean, ref_scale,
+                       scale_is_var, weight, eps, rmin, rmax, dmax, decay, fadein_decay, update, r, d, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_renorm_affine_fwd(const float* gamma, const float* beta, const float* r, const float* d, float* gamma_eff,
+                         float* beta_eff, int64_t rows, int C, void* stream) {
+    BG_REQUIRE(gamma && beta && r && d && gamma_eff && beta_eff && rows > 0 && C > 0, "bg_renorm_affine_fwd: bad argument");
+    const int64_t total = rows * C;
+    hipLaunchKernelGGL(renorm_affine_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), gamma, beta, r, d,
+                       gamma_eff, beta_eff, total, C, 0);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_renorm_affine_bwd(const float* dgamma_eff, const float* dbeta_eff, const float* r, const float* d, float* dgamma,
+                         int64_t rows, int C, void* stream) {
+    BG_REQUIRE(dgamma_eff && dbeta_eff && r && d && dgamma && rows > 0 && C > 0, "bg_renorm_affine_bwd: bad argument");
+    const int64_t total = rows * C;
+    hipLaunchKernelGGL(renorm_affine_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), dgamma_eff,
+                       dbeta_eff, r, d, dgamma, (float*)nullptr, total, C, 1);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

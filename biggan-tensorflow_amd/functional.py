@@ -455,7 +455,7 @@ class BnActFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, alpha, moving_mean, moving_var, momentum, eps, unbiased_mv, is_training,
-                reduce_fn, world):
+                reduce_fn, world, renorm=None):
         x = _c(x)
         N, H, W_, C = x.shape
         HW = H * W_
@@ -470,6 +470,14 @@ class BnActFn(Function):
             check(L.bg_bn_stats(f32(x), hip.ptr(sums), N * HW, C, stream()))
             if reduce_fn is not None:
                 reduce_fn(sums)
+            if renorm is not None:          # corrections first: they read the running statistics before any update
+                r_ = torch.empty(C, dtype=torch.float32, device=dev)
+                d_ = torch.empty(C, dtype=torch.float32, device=dev)
+                check(L.bg_renorm_coeffs(hip.ptr(sums), count, f32(renorm["ref_mean"]), f32(renorm["ref_scale"]),
+                                         int(renorm["scale_is_var"]), f32(renorm.get("weight")), eps,
+                                         renorm["rmin"], renorm["rmax"], renorm["dmax"], renorm["decay"],
+                                         renorm.get("fadein_decay", 0.9999), int(renorm["update"]), f32(r_), f32(d_), C,
+                                         stream()))
             check(L.bg_bn_finalize(hip.ptr(sums), count, eps, momentum, int(unbiased_mv), f32(mean), f32(rstd),
                                    f32(moving_mean), f32(moving_var), C, stream()))
         else:
@@ -480,6 +488,13 @@ class BnActFn(Function):
             check(L.bg_bn_finalize(hip.ptr(sums), 1.0, eps, 0.0, 0, f32(mean), f32(rstd), None, None, C, stream()))
         y = torch.empty_like(x)
         gamma_c, beta_c = _c(gamma), _c(beta)
+        ctx.renorm_rd = None
+        if renorm is not None and is_training:
+            g_eff, b_eff = torch.empty_like(gamma_c), torch.empty_like(beta_c)
+            check(L.bg_renorm_affine_fwd(f32(gamma_c), f32(beta_c), f32(r_), f32(d_), f32(g_eff), f32(b_eff),
+                                         gamma_c.numel() // C, C, stream()))
+            gamma_c, beta_c = g_eff, b_eff
+            ctx.renorm_rd = (r_, d_)
         check(L.bg_bn_apply_act_fwd(f32(x), f32(mean), f32(rstd), f32(gamma_c), f32(beta_c), per_sample,
                                     f32(alpha), f32(y), N, HW, C, stream()))
         ctx.x, ctx.mean, ctx.rstd = x, mean, rstd
@@ -510,6 +525,12 @@ class BnActFn(Function):
         cm = torch.empty(2 * C, dtype=torch.float32, device=dev)
         check(L.bg_bn_bwd_finalize(f32(part), f32(ctx.gamma_c), ps, ctx.count, f32(dgamma), f32(dbeta), f32(dalpha),
                                    f32(cm), N, C, stream()))
+        if ctx.renorm_rd is not None:       # gamma enters through r*gamma and d*gamma; beta unchanged
+            r_, d_ = ctx.renorm_rd
+            dg_eff = dgamma
+            dgamma = torch.empty_like(dg_eff)
+            check(L.bg_renorm_affine_bwd(f32(dg_eff), f32(dbeta), f32(r_), f32(d_), f32(dgamma), dg_eff.numel() // C, C,
+                                         stream()))
         if not ctx.is_training:
             cm.zero_()                      # population statistics are constants
         elif ctx.reduce_fn is not None:
@@ -531,7 +552,7 @@ class BnActFn(Function):
         db = deliver(beta, ctx.needs_input_grad[2], dbeta)
         da = deliver(alpha, ctx.needs_input_grad[3], dalpha) if alpha is not None else None
         ctx.x = None
-        return dx, dg, db, da, None, None, None, None, None, None, None, None
+        return dx, dg, db, da, None, None, None, None, None, None, None, None, None
 
 
 class PReluFn(Function):

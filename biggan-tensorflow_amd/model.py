@@ -4,9 +4,9 @@ eagerly on one MI355X per process.  One training iteration = D step then G step
 (BigGAN.py:1061-1084); each step is one "run" with its own z, DiffAugment draws and one spectral-norm
 power iteration per weight.
 
-Out-of-scope reference features (deep blocks, alternative heads, reconstruction
-heads, class conditioning, non-hinge losses, gradient penalty, renorm) are accepted as flags and
-rejected here with NotImplementedError.
+Out-of-scope reference features (alternative heads, reconstruction heads, label
+embeddings, mixed-kernel blocks, gradient-penalty losses) are accepted as flags and rejected here with
+NotImplementedError.
 """
 import copy
 import os
@@ -44,7 +44,9 @@ class GANBase(object):
         self.img_size = args.img_size
         self.bn_options = {"type": args.bn_type, "momentum": args.bn_momentum}       # GANBase.py:39-47
         if self.bn_options["type"] == 'batch_renorm':
-            raise NotImplementedError("--bn_type batch_renorm is outside the default hot path")
+            self.bn_options["renorm_clipping"] = {"rmax": args.bn_renorm_rmax, "dmax": args.bn_renorm_dmax}
+            self.bn_options["renorm_momentum"] = args.bn_renorm_momentum
+            self.bn_options["shared_renorm"] = args.bn_renorm_shared
         self.conv_options = {"padding_type": args.conv_padding, "sn": args.sn}       # GANBase.py:49-51
         self.da_policy = args.da_policy
         if self.da_policy == 'full':

@@ -574,7 +574,9 @@ def bn(x, opt={}, scope='batch_norm'):
     if type == 'bn' or type == 'batch_norm':
         return batch_norm(x, opt=opt, scope=scope)
     elif type == 'batch_renorm':
-        raise NotImplementedError("batch_renorm (ops.py:600) is outside the default hot path")
+        if scope == 'batch_norm':
+            scope = 'batch_renorm'
+        return batch_renorm(x, opt=opt, scope=scope)
     else:
         raise ValueError("Unknown BN type: " + str(type))
 
@@ -585,7 +587,9 @@ def cond_bn(x, z, opt={}, scope='batch_norm'):
     if type == 'bn' or type == 'batch_norm':
         return condition_batch_norm(x, z, opt=opt, scope=scope)
     elif type == 'batch_renorm':
-        raise NotImplementedError("condition_batch_renorm (ops.py:645) is outside the default hot path")
+        if scope == 'batch_norm':
+            scope = 'batch_renorm'
+        return condition_batch_renorm(x, z, opt=opt, scope=scope)
     else:
         raise ValueError("Unknown BN type: " + str(type))
 
@@ -603,9 +607,13 @@ def _act_alpha(act, x):
 
 def _bn_act(x, z, opt):
     """(cond_)bn followed by opt['act'], fused into one apply kernel when the activation is PReLU/ReLU."""
-    fused_types = ('bn', 'batch_norm', 'batch_norm_broken_renorm')
+    fused_types = ('bn', 'batch_norm', 'batch_norm_broken_renorm', 'batch_renorm')
     if opt.get("bn", {}).get("type", "bn") in fused_types and opt["act"] in (prelu, relu):
         type, scope = _bn_type(opt, 'batch_norm')
+        if type == 'batch_renorm':
+            if z is None:
+                return batch_renorm(x, opt=opt, scope='batch_renorm', _act=opt["act"])
+            return condition_batch_renorm(x, z, opt=opt, scope='batch_renorm', _act=opt["act"])
         if z is None:
             return batch_norm(x, opt=opt, scope=scope, _act=opt["act"])
         return condition_batch_norm(x, z, opt=opt, scope=scope, _act=opt["act"])
@@ -631,8 +639,41 @@ def batch_norm(x, opt={}, scope='batch_norm', _act=None):
                             _run.reduce_fn, _run.world)
 
 
-def batch_renorm(x, opt={}, scope='batch_renorm'):
-    raise NotImplementedError("batch_renorm (ops.py:600) is outside the default hot path")
+def normalize_renorm_clipping_params(renorm_clipping):
+    """ops.py:587-597."""
+    if "rmax" not in renorm_clipping:
+        renorm_clipping["rmax"] = 1.5
+    if "dmax" not in renorm_clipping:
+        renorm_clipping["dmax"] = 0.5
+    if "rmax" in renorm_clipping and "rmin" not in renorm_clipping:
+        renorm_clipping["rmin"] = 1.0 / renorm_clipping["rmax"]
+    return renorm_clipping
+
+
+def batch_renorm(x, opt={}, scope='batch_renorm', _act=None):
+    """ops.py:600-609: tf.layers.batch_normalization(renorm=True, renorm_momentum, renorm_clipping), with the
+    TF 1.15 layer's variables and update rule: ``renorm_mean`` / ``renorm_stddev`` (no zero-debias weights),
+    corrections against max(renorm_stddev, sqrt(eps)) read before the update, the non-fused moving-variance
+    update (biased batch variance), r = 1 / d = 0 at inference."""
+    clip = normalize_renorm_clipping_params(dict(opt.get("bn", {}).get("renorm_clipping", {})))
+    C = x.shape[-1]
+    with variable_scope(scope):
+        gamma = get_variable("gamma", [C], initializer=S.constant_initializer(1.0))
+        beta = get_variable("beta", [C], initializer=S.constant_initializer(0.0))
+        mm = get_variable("moving_mean", [C], initializer=S.constant_initializer(0.0), trainable=False)
+        mv = get_variable("moving_variance", [C], initializer=S.constant_initializer(1.0), trainable=False)
+        rmean = get_variable("renorm_mean", [C], initializer=S.constant_initializer(0.0), trainable=False)
+        rstd = get_variable("renorm_stddev", [C], initializer=S.constant_initializer(1.0), trainable=False)
+    alpha = None
+    if _act is not None:
+        _, alpha = _act_alpha(_act, x)
+    if _is_meta(x):
+        return _meta(x.shape)
+    renorm = dict(ref_mean=rmean, ref_scale=rstd, scale_is_var=0, weight=None, update=1,
+                  rmin=clip["rmin"], rmax=clip["rmax"], dmax=clip["dmax"],
+                  decay=opt.get("bn", {}).get("renorm_momentum", 0.9))
+    return Fn.BnActFn.apply(x, gamma, beta, alpha, mm, mv, opt.get("bn", {}).get("momentum", 0.98), 1e-05, False,
+                            bool(opt["is_training"]), _run.reduce_fn, _run.world, renorm)
 
 
 def condition_batch_norm(x, z, opt={}, scope='batch_norm', _act=None):
@@ -654,8 +695,42 @@ def condition_batch_norm(x, z, opt={}, scope='batch_norm', _act=None):
                             bool(opt["is_training"]), _run.reduce_fn, _run.world)
 
 
-def condition_batch_renorm(x, z, opt={}, scope='batch_renorm'):
-    raise NotImplementedError("condition_batch_renorm (ops.py:645) is outside the default hot path")
+def condition_batch_renorm(x, z, opt={}, scope='batch_renorm', _act=None):
+    """ops.py:645-715.  Not shared (default): separate renorm_mean / renorm_var / renorm_weight running statistics
+    with decay ``renorm_momentum``, faded in by renorm_weight; the population statistics then ALSO use
+    ``renorm_momentum`` as their decay (ops.py:658-659).  Shared: the corrections are measured against
+    pop_mean / pop_var themselves (weight 1), which keep the ``momentum`` decay."""
+    with variable_scope(scope):
+        c = x.shape[-1]
+        bn_opt = opt.get("bn", {})
+        clip = normalize_renorm_clipping_params(dict(bn_opt.get("renorm_clipping", {})))
+        test_decay = bn_opt.get("momentum", 0.98)
+        renorm_decay = bn_opt.get("renorm_momentum", 0.9)
+        shared = bn_opt.get("shared_renorm", False)
+        renorm_fadein_decay = bn_opt.get("renorm_fadein_decay", 0.9999)
+        if not shared:
+            test_decay = renorm_decay
+        epsilon = 1e-05
+        test_mean = get_variable("pop_mean", shape=[c], initializer=S.constant_initializer(0.0), trainable=False)
+        test_var = get_variable("pop_var", shape=[c], initializer=S.constant_initializer(1.0), trainable=False)
+        if not shared:
+            renorm_mean = get_variable("renorm_mean", shape=[c], initializer=S.constant_initializer(0.0), trainable=False)
+            renorm_var = get_variable("renorm_var", shape=[c], initializer=S.constant_initializer(1.0), trainable=False)
+            renorm_weight = get_variable("renorm_weight", shape=[], initializer=S.constant_initializer(0.0), trainable=False)
+        else:
+            renorm_mean, renorm_var, renorm_weight = test_mean, test_var, None
+        beta = fully_connected(z, units=c, scope='beta', opt=opt)
+        gamma = fully_connected(z, units=c, scope='gamma', opt=opt)
+    alpha = None
+    if _act is not None:
+        _, alpha = _act_alpha(_act, x)
+    if _is_meta(x):
+        return _meta(x.shape)
+    renorm = dict(ref_mean=renorm_mean, ref_scale=renorm_var, scale_is_var=1, weight=renorm_weight,
+                  update=int(not shared), rmin=clip["rmin"], rmax=clip["rmax"], dmax=clip["dmax"],
+                  decay=renorm_decay, fadein_decay=renorm_fadein_decay)
+    return Fn.BnActFn.apply(x, gamma, beta, alpha, test_mean, test_var, test_decay, epsilon, False,
+                            bool(opt["is_training"]), _run.reduce_fn, _run.world, renorm)
 
 
 def spectral_norm(w, iteration=1, _shape_only=False):

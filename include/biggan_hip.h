@@ -214,6 +214,30 @@ int bg_bn_apply_act_bwd_dx(const float* x, const float* dy, const float* mean, c
 int bg_bn_bwd_finalize(const float* part, const float* gamma, int per_sample, double count,
                        float* dgamma, float* dbeta, float* dalpha, float* cm, int N, int C, void* stream);
 
+/* Batch renormalisation (ops.py:600-609 tf.layers.batch_normalization(renorm=True); ops.py:645-715
+ * condition_batch_renorm).  The normalisation itself is the batch-norm above with the affine pair replaced by
+ *   gamma_eff = r * gamma ,  beta_eff = beta + d * gamma        (r, d per channel, constants for the gradient)
+ * bg_renorm_coeffs turns the batch sums of bg_bn_stats into the clipped corrections, measured against running
+ * statistics that are read BEFORE any update of this run:
+ *   sigma = sqrt(var + eps) ; sigma_ref = sqrt(ref_scale + eps)            (scale_is_var = 1, ops.py:688-689)
+ *                             sigma_ref = max(ref_scale, sqrt(eps))        (scale_is_var = 0, Keras renorm_stddev)
+ *   sigma_w = w * sigma_ref + (1-w) * sigma ;  mean_w = w * ref_mean + (1-w) * mean     (ops.py:690-691;
+ *             w = *weight, or 1 when weight == NULL: --bn_renorm_shared / Keras)
+ *   r = clip(sigma / sigma_w, rmin, rmax) ;  d = clip((mean - mean_w) / sigma_w, -dmax, dmax)   (ops.py:692-693)
+ * update = 1 also moves the running statistics (ops.py:701-703):
+ *   ref_mean  <- ref_mean  * decay + mean * (1-decay)
+ *   ref_scale <- ref_scale * decay + (scale_is_var ? var : sigma) * (1-decay)
+ *   *weight   <- *weight * fadein_decay + (1 - fadein_decay)
+ * bg_renorm_affine_fwd/bwd: the [rows, C] (conditional, rows = batch) or [1, C] affine pair and the gradient
+ *   dgamma = r * dgamma_eff + d * dbeta_eff   (dbeta = dbeta_eff). */
+int bg_renorm_coeffs(const double* sums, double count, float* ref_mean, float* ref_scale, int scale_is_var,
+                     float* weight, float eps, float rmin, float rmax, float dmax, float decay, float fadein_decay,
+                     int update, float* r, float* d, int C, void* stream);
+int bg_renorm_affine_fwd(const float* gamma, const float* beta, const float* r, const float* d,
+                         float* gamma_eff, float* beta_eff, int64_t rows, int C, void* stream);
+int bg_renorm_affine_bwd(const float* dgamma_eff, const float* dbeta_eff, const float* r, const float* d,
+                         float* dgamma, int64_t rows, int C, void* stream);
+
 /* stand-alone PReLU (ops.py:532-537): y = x>0 ? x : alpha_c*x ; bwd returns dx and per-channel
  * partial dalpha accumulated with atomics into dalpha[C] (caller zeroes). */
 int bg_prelu_fwd(const float* x, const float* alpha, float* y, int64_t rows, int C, void* stream);

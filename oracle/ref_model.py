@@ -28,6 +28,11 @@ class Config:
         self.bias_in_d = False
         self.bias_in_sa = True
         self.bn_momentum = 0.98
+        self.bn_type = "batch_norm"           # main.py:43
+        self.bn_renorm_rmax = 1.5             # main.py:45-48
+        self.bn_renorm_dmax = 0.5
+        self.bn_renorm_momentum = 0.9
+        self.bn_renorm_shared = False
         self.g_regularization = "ortho_cosine"
         self.g_regularization_factor = 1e-4
         self.conv_padding = "reflect"
@@ -113,7 +118,9 @@ def _conv_opt(cfg, training, generator):
     opt = {"sn": cfg.sn, "padding_type": cfg.conv_padding, "bn_momentum": cfg.bn_momentum,
            "self_attention_bias": cfg.bias_in_sa, "regularizer": None, "act": cfg.activation,
            "bn_in_d": cfg.bn_in_d, "upsampling_method": cfg.upsampling_method, "g_conv": cfg.g_conv,
-           "downsampling_method": cfg.downsampling_method}
+           "downsampling_method": cfg.downsampling_method, "bn_type": cfg.bn_type,
+           "bn_renorm_rmax": cfg.bn_renorm_rmax, "bn_renorm_dmax": cfg.bn_renorm_dmax,
+           "bn_renorm_momentum": cfg.bn_renorm_momentum, "bn_renorm_shared": cfg.bn_renorm_shared}
     if generator and training and cfg.g_regularization != "none":           # BigGAN.py:257-274
         opt["regularizer"] = {"scale": cfg.g_regularization_factor, "type": cfg.g_regularization}
     return opt
@@ -439,3 +446,13 @@ def perturb_for_parity(vs, seed=7):
             elif leaf == "kernel":
                 # larger weights so logits / gradients are not vanishingly small
                 v.mul_(4.0)
+            elif "/batch_renorm/" in k and leaf in ("renorm_mean", "pop_mean"):
+                # batch renorm: at its initial state (renorm_weight 0, mean 0, var 1) the corrections are r = 1,
+                # d = 0; start from a mid-training state so clipped and unclipped corrections both occur
+                v.copy_(torch.tensor(rng.normal(0, 0.3, tuple(v.shape)), dtype=v.dtype))
+            elif "/batch_renorm/" in k and leaf in ("renorm_var", "pop_var"):
+                v.copy_(torch.tensor(rng.uniform(0.05, 2.5, tuple(v.shape)), dtype=v.dtype))
+            elif leaf == "renorm_stddev":
+                v.copy_(torch.tensor(rng.uniform(0.2, 1.6, tuple(v.shape)), dtype=v.dtype))
+            elif leaf == "renorm_weight":
+                v.fill_(0.7)

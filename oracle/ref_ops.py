@@ -91,7 +91,8 @@ class VarStore:
 
 def _is_state_name(name):
     leaf = name.rsplit("/", 1)[-1]
-    return leaf in ("u", "pop_mean", "pop_var", "moving_mean", "moving_variance")
+    return leaf in ("u", "pop_mean", "pop_var", "moving_mean", "moving_variance",
+                    "renorm_mean", "renorm_var", "renorm_weight", "renorm_stddev")
 
 
 def round_up(val, multiple):                       # utils.py:335-336
@@ -313,9 +314,101 @@ def global_sum_pooling(x):                        # ops.py:503-506
 BN_EPS = 1e-5
 
 
+def _renorm_scope(scope):
+    """ops.py:556-558 / 573-575: the default scope 'batch_norm' becomes 'batch_renorm'."""
+    assert scope.endswith("batch_norm"), scope
+    return scope[:-len("batch_norm")] + "batch_renorm"
+
+
+def _renorm_clipping(opt):
+    """ops.py:587-597 with GANBase.py:42-45."""
+    rmax = opt.get("bn_renorm_rmax", 1.5)
+    return 1.0 / rmax, rmax, opt.get("bn_renorm_dmax", 0.5)
+
+
+def condition_batch_renorm(vs, scope, x, z, opt, is_training=True):
+    """ops.py:645-715."""
+    c = x.shape[-1]
+    rmin, rmax, dmax = _renorm_clipping(opt)
+    test_decay = opt.get("bn_momentum", 0.98)
+    renorm_decay = opt.get("bn_renorm_momentum", 0.9)
+    shared = opt.get("bn_renorm_shared", False)
+    fadein = 0.9999                                             # ops.py:656 (no flag sets it)
+    if not shared:
+        test_decay = renorm_decay                               # ops.py:658-659
+    pop_mean = vs.get(scope + "/pop_mean", (c,), 0.0, trainable=False)
+    pop_var = vs.get(scope + "/pop_var", (c,), 1.0, trainable=False)
+    if not shared:
+        renorm_mean = vs.get(scope + "/renorm_mean", (c,), 0.0, trainable=False)
+        renorm_var = vs.get(scope + "/renorm_var", (c,), 1.0, trainable=False)
+        renorm_weight = vs.get(scope + "/renorm_weight", (), 0.0, trainable=False)
+    else:
+        renorm_mean, renorm_var, renorm_weight = pop_mean, pop_var, 1.0
+    beta = fully_connected(vs, scope + "/beta", z, c, opt).reshape(-1, 1, 1, c)
+    gamma = fully_connected(vs, scope + "/gamma", z, c, opt).reshape(-1, 1, 1, c)
+    if not is_training:
+        inv = torch.rsqrt(pop_var + BN_EPS) * gamma
+        return x * inv + (beta - pop_mean * inv)
+    mean = x.mean(dim=(0, 1, 2))
+    var = ((x - mean) ** 2).mean(dim=(0, 1, 2))
+    sigma = torch.sqrt(var + BN_EPS)
+    renorm_sigma = torch.sqrt(renorm_var + BN_EPS)
+    w_sigma = renorm_weight * renorm_sigma + (1 - renorm_weight) * sigma
+    w_mean = renorm_weight * renorm_mean + (1 - renorm_weight) * mean
+    r = torch.clamp(sigma / w_sigma, rmin, rmax).detach()
+    d = torch.clamp((mean - w_mean) / w_sigma, -dmax, dmax).detach()
+    vs.assign(scope + "/pop_mean", pop_mean * test_decay + mean * (1 - test_decay))
+    vs.assign(scope + "/pop_var", pop_var * test_decay + var * (1 - test_decay))
+    if not shared:
+        vs.assign(scope + "/renorm_mean", renorm_mean * renorm_decay + mean * (1 - renorm_decay))
+        vs.assign(scope + "/renorm_var", renorm_var * renorm_decay + var * (1 - renorm_decay))
+        vs.assign(scope + "/renorm_weight", renorm_weight * fadein + 1.0 * (1 - fadein))
+    # tf.nn.batch_normalization(x, batch_mean, batch_var, beta + d*gamma, r*gamma, eps)
+    inv = torch.rsqrt(var + BN_EPS) * (r * gamma)
+    return x * inv + ((beta + d * gamma) - mean * inv)
+
+
+def batch_renorm(vs, scope, x, opt, is_training=True):
+    """ops.py:600-609: tf.layers.batch_normalization(renorm=True) as the TF 1.15 layer computes it
+    (keras/layers/normalization.py, _renorm_correction_and_moments): variables renorm_mean / renorm_stddev,
+    r = sigma / max(renorm_stddev, sqrt(eps)), d = (mean - renorm_mean) / max(...), clipped, stop-gradient,
+    measured BEFORE the moving averages move; scale = r*gamma, offset = d*gamma + beta; non-fused layer, so
+    moving_variance follows the biased batch variance.  Two instantiations in one run (--bn_in_d: real, fake)
+    are taken in that order (TF leaves the order of their reads and updates open)."""
+    c = x.shape[-1]
+    rmin, rmax, dmax = _renorm_clipping(opt)
+    decay = opt.get("bn_momentum", 0.98)
+    rdecay = opt.get("bn_renorm_momentum", 0.9)
+    gamma = vs.get(scope + "/gamma", (c,), 1.0)
+    beta = vs.get(scope + "/beta", (c,), 0.0)
+    mm = vs.get(scope + "/moving_mean", (c,), 0.0, trainable=False)
+    mv = vs.get(scope + "/moving_variance", (c,), 1.0, trainable=False)
+    vs.get(scope + "/renorm_mean", (c,), 0.0, trainable=False)
+    vs.get(scope + "/renorm_stddev", (c,), 1.0, trainable=False)
+    if not is_training:
+        inv = torch.rsqrt(mv + BN_EPS) * gamma
+        return x * inv + (beta - mm * inv)
+    mean = x.mean(dim=(0, 1, 2))
+    var = ((x - mean) ** 2).mean(dim=(0, 1, 2))
+    sigma = torch.sqrt(var + BN_EPS)
+    rm_c, rs_c = vs.current(scope + "/renorm_mean"), vs.current(scope + "/renorm_stddev")
+    ref = torch.clamp(rs_c, min=BN_EPS ** 0.5)
+    r = torch.clamp(sigma / ref, rmin, rmax).detach()
+    d = torch.clamp((mean - rm_c) / ref, -dmax, dmax).detach()
+    vs.assign(scope + "/renorm_mean", rm_c * rdecay + mean.detach() * (1 - rdecay))
+    vs.assign(scope + "/renorm_stddev", rs_c * rdecay + sigma.detach() * (1 - rdecay))
+    mm_c, mv_c = vs.current(scope + "/moving_mean"), vs.current(scope + "/moving_variance")
+    vs.assign(scope + "/moving_mean", mm_c * decay + mean * (1 - decay))
+    vs.assign(scope + "/moving_variance", mv_c * decay + var * (1 - decay))
+    inv = torch.rsqrt(var + BN_EPS) * (r * gamma)
+    return x * inv + ((beta + d * gamma) - mean * inv)
+
+
 def condition_batch_norm(vs, scope, x, z, opt, is_training=True):
     """ops.py:611-643.  beta/gamma = SN dense of z (bias init 0; gamma is NOT 1 + ...);
     training: biased batch moments over (B,H,W), EMA of pop stats with decay ``momentum``."""
+    if opt.get("bn_type", "batch_norm") == "batch_renorm":        # cond_bn dispatch, ops.py:563-578
+        return condition_batch_renorm(vs, _renorm_scope(scope), x, z, opt, is_training)
     c = x.shape[-1]
     decay = opt.get("bn_momentum", 0.98)
     pop_mean = vs.get(scope + "/pop_mean", (c,), 0.0, trainable=False)
@@ -338,6 +431,8 @@ def batch_norm(vs, scope, x, opt, is_training=True):
     """ops.py:580-585: tf.layers.batch_normalization(momentum, eps=1e-5).  Normalises with the
     biased batch variance; the fused kernel's moving-variance update uses the Bessel-corrected
     one (TF documentation; affects sampling only)."""
+    if opt.get("bn_type", "batch_norm") == "batch_renorm":        # bn dispatch, ops.py:546-561
+        return batch_renorm(vs, _renorm_scope(scope), x, opt, is_training)
     c = x.shape[-1]
     decay = opt.get("bn_momentum", 0.98)
     gamma = vs.get(scope + "/gamma", (c,), 1.0)

@@ -444,6 +444,71 @@ def test_bn_act_fwd_bwd(N, H, C, per_sample, with_alpha):
     assert rel_err(t2n(mv), mv0 * 0.98 + var.detach().numpy() * vfac * 0.02) < TOL
 
 
+@pytest.mark.parametrize("N,H,C,per_sample,scale_is_var,weight", [
+    (4, 8, 16, True, 1, 0.7), (3, 4, 40, True, 1, None), (2, 8, 8, False, 0, None), (5, 2, 1024, True, 1, 0.0)])
+def test_bn_renorm_fwd_bwd(N, H, C, per_sample, scale_is_var, weight):
+    """bg_renorm_coeffs / bg_renorm_affine_* inside BnActFn (ops.py:600-609, 645-715) against a float64 torch
+    restatement: clipped and unclipped r / d, stop-gradient, running-statistics and fade-in updates."""
+    Fn = _fn()
+    rng = np.random.default_rng(N + H + C)
+    x = rng.standard_normal((N, H, H, C)) * 1.5 + 0.3
+    gshape = (N, C) if per_sample else (C,)
+    gamma, beta = rng.standard_normal(gshape), rng.standard_normal(gshape)
+    alpha = rng.uniform(0.05, 0.4, C)
+    mm0, mv0 = rng.standard_normal(C), rng.uniform(0.5, 2, C)
+    rm0 = rng.normal(0.3, 0.6, C)
+    rs0 = rng.uniform(0.3, 6.0, C) if scale_is_var else rng.uniform(0.7, 3.0, C)      # batch sigma is about 1.5
+    if not scale_is_var:
+        rs0[0] = 1e-4                                        # below sqrt(eps): the Keras floor
+    rmin, rmax, dmax, decay, fade, eps = 1 / 1.5, 1.5, 0.5, 0.9, 0.9999, 1e-5
+    xt, gt, bt, at = (torch.tensor(a, requires_grad=True) for a in (x, gamma, beta, alpha))
+    mean = xt.mean(dim=(0, 1, 2))
+    var = ((xt - mean) ** 2).mean(dim=(0, 1, 2))
+    sigma = torch.sqrt(var + eps)
+    w = 1.0 if weight is None else weight
+    sref = torch.sqrt(torch.tensor(rs0) + eps) if scale_is_var else torch.clamp(torch.tensor(rs0), min=eps ** 0.5)
+    sw = w * sref + (1 - w) * sigma
+    mw = w * torch.tensor(rm0) + (1 - w) * mean
+    r = torch.clamp(sigma / sw, rmin, rmax).detach()
+    d = torch.clamp((mean - mw) / sw, -dmax, dmax).detach()
+    if w > 0:
+        assert 0 < int((r == rmax).sum() + (r == rmin).sum()) < C and 0 < int((d.abs() == dmax).sum()) < C
+    gb = gt.reshape(-1, 1, 1, C) if per_sample else gt
+    bb = bt.reshape(-1, 1, 1, C) if per_sample else bt
+    inv = torch.rsqrt(var + eps) * (r * gb)
+    pre = xt * inv + ((bb + d * gb) - mean * inv)
+    yr = torch.relu(pre) + at * (pre - pre.abs()) * 0.5
+    g = rng.standard_normal(x.shape)
+    yr.backward(torch.tensor(g))
+    xc, gc, bc, ac = cu(x, True), cu(gamma, True), cu(beta, True), cu(alpha, True)
+    mm, mv, rm, rs = cu(mm0), cu(mv0), cu(rm0), cu(rs0)
+    wt = None if weight is None else torch.full((), weight, dtype=torch.float32, device="cuda")
+    renorm = dict(ref_mean=rm, ref_scale=rs, scale_is_var=scale_is_var, weight=wt, update=1, rmin=rmin, rmax=rmax,
+                  dmax=dmax, decay=decay, fadein_decay=fade)
+    y = Fn.BnActFn.apply(xc, gc, bc, ac, mm, mv, 0.98, eps, False, True, None, 1, renorm)
+    y.backward(cu(g))
+    assert rel_err(t2n(y), yr.detach().numpy()) < TOL
+    assert rel_err(t2n(xc.grad), xt.grad.numpy()) < 1e-4
+    assert rel_err(t2n(gc.grad), gt.grad.numpy()) < 5e-5
+    assert rel_err(t2n(bc.grad), bt.grad.numpy()) < 5e-5
+    assert rel_err(t2n(ac.grad), at.grad.numpy()) < 5e-5
+    assert rel_err(t2n(mm), mm0 * 0.98 + mean.detach().numpy() * 0.02) < TOL
+    assert rel_err(t2n(mv), mv0 * 0.98 + var.detach().numpy() * 0.02) < TOL
+    assert rel_err(t2n(rm), rm0 * decay + mean.detach().numpy() * (1 - decay)) < TOL
+    moved = var.detach().numpy() if scale_is_var else sigma.detach().numpy()
+    assert rel_err(t2n(rs), rs0 * decay + moved * (1 - decay)) < TOL
+    if weight is not None:
+        assert abs(float(wt) - (weight * fade + (1 - fade))) < 1e-6
+    # inference: population statistics, no corrections, nothing moves
+    before = [t.clone() for t in (mm, mv, rm, rs)]
+    yi = Fn.BnActFn.apply(xc.detach(), gc.detach(), bc.detach(), None, mm, mv, 0.98, eps, False, False, None, 1, renorm)
+    gi = gamma.reshape(-1, 1, 1, C) if per_sample else gamma
+    bi = beta.reshape(-1, 1, 1, C) if per_sample else beta
+    ref_i = (x - t2n(mm).astype(np.float64)) / np.sqrt(t2n(mv).astype(np.float64) + eps) * gi + bi
+    assert rel_err(t2n(yi), ref_i) < TOL
+    assert all(torch.equal(a, b) for a, b in zip(before, (mm, mv, rm, rs)))
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 8, 3), (4, 4, 4, 64), (7, 33)])
 def test_prelu(shape):
     Fn = _fn()

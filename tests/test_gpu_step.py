@@ -382,6 +382,11 @@ def test_sample_with_ema_weights():
     (dict(g_no_last_resblock=True, upsampling_method="resize_conv"),
      dict(g_no_last_resblock="true", upsampling_method="resize_conv")),
     (dict(n_labels=6, d_cls_dense_layers=True), dict(n_labels=6, d_cls_dense_layers="true")),
+    (dict(bn_type="batch_renorm"), dict(bn_type="batch_renorm")),
+    (dict(bn_type="batch_renorm", bn_renorm_shared=True, bn_renorm_rmax=2.0, bn_renorm_dmax=1.0),
+     dict(bn_type="batch_renorm", bn_renorm_shared="true", bn_renorm_rmax=2.0, bn_renorm_dmax=1.0)),
+    (dict(bn_type="batch_renorm", bn_in_d=True, bn_renorm_momentum=0.8),
+     dict(bn_type="batch_renorm", bn_in_d="true", bn_renorm_momentum=0.8)),
 ])
 def test_step_parity_non_default_flags(okw, hkw):
     """--activation relu / lrelu (BigGAN.py:71-83), --conv_padding zero (TF SAME,

@@ -156,7 +156,7 @@ def test_sample_grid_png(tmp_path):
 
 def test_out_of_scope_flags_rejected_at_build():
     for extra in (["--g_final_layer", "true"], ["--cls_embedding", "true"], ["--gan_type", "ra-dragan"], ["--g_final_layer", "true"],
-                  ["--bn_type", "batch_renorm"], ["--z_reconstruct", "true"]):
+                  ["--z_reconstruct", "true"]):
         argv = ["--gan_type", "hinge", "--img_size", "64"] + extra
         with pytest.raises(NotImplementedError):
             model.BigGAN(M.parse_args(argv, make_dirs=False), device="cpu", store=S.VariableStore("cpu"))
@@ -213,6 +213,26 @@ def test_manifest_matches_oracle(size):
     gan.generator(torch.empty(2, 1, 1, gan.z_dim, device="meta"))
     gan.discriminator(img)
     assert len(store.vars) == n
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_batch_renorm_manifest_matches_oracle(shared):
+    """--bn_type batch_renorm (ops.py:556-559, 573-576, 600-609, 645-715): the 'batch_renorm' scopes, the extra running
+    statistics of the non-shared form and the Keras layer's renorm_mean / renorm_stddev under --bn_in_d."""
+    argv = ["--gan_type", "hinge", "--img_size", "64", "--ch", "8", "--bn_type", "batch_renorm", "--bn_in_d", "true",
+            "--bn_renorm_shared", str(shared).lower()]
+    store = S.VariableStore("cpu")
+    gan = model.BigGAN(M.parse_args(argv, make_dirs=False), device="cpu", store=store)
+    gan.discriminator(gan.generator(torch.empty(2, 1, 1, gan.z_dim, device="meta")))
+    tr = RM.Trainer(RM.Config(img_size=64, ch=8, batch_size=2, bn_type="batch_renorm", bn_in_d=True,
+                              bn_renorm_shared=shared), torch.float32).build()
+    mine = {k: tuple(v.shape) for k, v in store.vars.items()}
+    ref = {k: tuple(v.shape) for k, v in tr.vs.vars.items()}
+    assert mine == ref
+    assert {k for k in mine if store.trainable[k]} == {k for k in ref if tr.vs.trainable[k]}
+    assert not any(k.endswith("/batch_norm/pop_mean") for k in mine)
+    assert ("generator/resblock_up_8/res1/batch_renorm/renorm_weight" in mine) == (not shared)
+    assert "discriminator/resblock_down_1/res1/batch_renorm/renorm_stddev" in mine
 
 
 def test_arena_packing_on_cpu():

@@ -378,3 +378,67 @@ def test_tf_conv2d_transpose_unit_test_closed_forms():
             w = torch.tensor(f)
             yt = F.conv_transpose2d(torch.tensor(x).permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), stride=1, padding=1)
             assert np.array_equal(yt.permute(0, 2, 3, 1).numpy(), y)
+
+
+def test_batch_renorm_reductions_and_hand_case():
+    """ops.py:645-715 / 600-609: (1) at its initial state (renorm_weight = 0) condition_batch_renorm IS
+    condition_batch_norm; (2) the Keras form with renorm statistics equal to the batch's is plain batch norm;
+    (3) a hand-computed channel: batch mean 1, var 4 (sigma 2), renorm mean 0, renorm var 1, weight 1 ->
+    r = clip(2, 2/3, 1.5) = 1.5, d = clip(1, -.5, .5) = 0.5, y = xhat * 1.5 * gamma + beta + 0.5 * gamma;
+    (4) r and d carry no gradient."""
+    torch.manual_seed(0)
+    opt = {"sn": False, "bn_momentum": 0.98}
+    x = torch.randn(3, 4, 4, 5, dtype=torch.float64)
+    z = torch.randn(3, 7, dtype=torch.float64)
+    vs = R.VarStore(torch.float64, 1)
+    a = R.condition_batch_norm(vs, "g/batch_norm", x, z, opt)
+    vr = R.VarStore(torch.float64, 1)
+    b = R.condition_batch_renorm(vr, "g/batch_renorm", x, z, opt)
+    assert torch.allclose(a, b, atol=1e-14)
+    assert float(vr.state_updates["g/batch_renorm/renorm_weight"]) == pytest.approx(1e-4)
+    # the population statistics of the non-shared form decay with renorm_momentum (0.9), ops.py:658-659
+    mean = x.mean(dim=(0, 1, 2))
+    assert torch.allclose(vr.state_updates["g/batch_renorm/pop_mean"], 0.1 * mean)
+
+    vk = R.VarStore(torch.float64, 1)
+    var = ((x - mean) ** 2).mean(dim=(0, 1, 2))
+    vk.get("d/batch_renorm/renorm_mean", (5,), 0.0, trainable=False)
+    vk.get("d/batch_renorm/renorm_stddev", (5,), 1.0, trainable=False)
+    with torch.no_grad():
+        vk.vars["d/batch_renorm/renorm_mean"].copy_(mean)
+        vk.vars["d/batch_renorm/renorm_stddev"].copy_(torch.sqrt(var + 1e-5))
+    k = R.batch_renorm(vk, "d/batch_renorm", x, opt)
+    plain = R.batch_norm(R.VarStore(torch.float64, 1), "d/batch_norm", x, opt)
+    assert torch.allclose(k, plain, atol=1e-12)
+
+    xs = torch.tensor([-1.0, 3.0], dtype=torch.float64).reshape(2, 1, 1, 1)          # mean 1, var 4
+    vh = R.VarStore(torch.float64, 1)
+    vh.get("h/batch_renorm/renorm_weight", (), 0.0, trainable=False)
+    with torch.no_grad():
+        vh.vars["h/batch_renorm/renorm_weight"].fill_(1.0)
+    zh = torch.ones(2, 1, dtype=torch.float64)
+    y = R.condition_batch_renorm(vh, "h/batch_renorm", xs, zh, opt)
+    gam = (zh @ vh.vars["h/batch_renorm/gamma/kernel"] + vh.vars["h/batch_renorm/gamma/bias"]).reshape(2, 1, 1, 1)
+    bet = (zh @ vh.vars["h/batch_renorm/beta/kernel"] + vh.vars["h/batch_renorm/beta/bias"]).reshape(2, 1, 1, 1)
+    xhat = (xs - 1.0) / np.sqrt(4.0 + 1e-5)
+    assert torch.allclose(y, xhat * 1.5 * gam + bet + 0.5 * gam, atol=1e-12)
+
+    # stop-gradient: d(sum y)/dx through a frozen-(r,d) restatement equals autograd's
+    xr = x.clone().requires_grad_(True)
+    v4 = R.VarStore(torch.float64, 1)
+    v4.get("q/batch_renorm/renorm_weight", (), 0.0, trainable=False)
+    with torch.no_grad():
+        v4.vars["q/batch_renorm/renorm_weight"].fill_(0.5)
+    y4 = R.condition_batch_renorm(v4, "q/batch_renorm", xr, z, opt)
+    g_auto, = torch.autograd.grad((y4 * y4).sum(), xr)
+    with torch.no_grad():
+        m0 = x.mean(dim=(0, 1, 2)); v0 = ((x - m0) ** 2).mean(dim=(0, 1, 2)); s0 = torch.sqrt(v0 + 1e-5)
+        sw = 0.5 * np.sqrt(1 + 1e-5) + 0.5 * s0
+        r0 = torch.clamp(s0 / sw, 1 / 1.5, 1.5); d0 = torch.clamp((m0 - 0.5 * m0) / sw, -0.5, 0.5)
+    xq = x.clone().requires_grad_(True)
+    gam = (z @ v4.vars["q/batch_renorm/gamma/kernel"] + v4.vars["q/batch_renorm/gamma/bias"]).reshape(3, 1, 1, 5)
+    bet = (z @ v4.vars["q/batch_renorm/beta/kernel"] + v4.vars["q/batch_renorm/beta/bias"]).reshape(3, 1, 1, 5)
+    mq = xq.mean(dim=(0, 1, 2)); vq = ((xq - mq) ** 2).mean(dim=(0, 1, 2))
+    yq = (xq - mq) * torch.rsqrt(vq + 1e-5) * (r0 * gam) + bet + d0 * gam
+    g_frozen, = torch.autograd.grad((yq * yq).sum(), xq)
+    assert torch.allclose(g_auto, g_frozen, atol=1e-10)
