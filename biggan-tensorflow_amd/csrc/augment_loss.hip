@@ -367,7 +367,8 @@ __global__ __launch_bounds__(AL_BLOCK) void ortho_lowrank_finish_kernel(float* _
 //   Gradients include the coupling through the means: dL/dreal_i = (phi_r'(u_i) - mean_j phi_f'(v_j)) / N_r.
 // Single-block kernels (logits are [B, 1]); sums are exchanged across data-parallel ranks by the caller.
 // ------------------------------------------------------------------------------------------
-enum { GL_HINGE = 0, GL_LSGAN = 1, GL_GAN = 2, GL_RA_LSGAN = 3, GL_RA_GAN = 4, GL_RA_HINGE = 5 };
+enum { GL_HINGE = 0, GL_LSGAN = 1, GL_GAN = 2, GL_RA_LSGAN = 3, GL_RA_GAN = 4, GL_RA_HINGE = 5, GL_WGAN = 6 };
+__device__ __forceinline__ bool gl_relativistic(int kind) { return kind >= GL_RA_LSGAN && kind <= GL_RA_HINGE; }
 
 __device__ __forceinline__ float gl_softplus(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
 __device__ __forceinline__ float gl_sigmoid(float x) {
@@ -377,7 +378,7 @@ __device__ __forceinline__ float gl_sigmoid(float x) {
 
 // value and derivative of the real-side / fake-side term
 __device__ __forceinline__ void gl_phi(int kind, int gen, bool real_side, float x, float* val, float* der) {
-    const bool ra = kind >= GL_RA_LSGAN;
+    const bool ra = gl_relativistic(kind);
     if (real_side && gen && !ra) {          // non-relativistic generator losses do not look at the real logits
         *val = 0.f;
         *der = 0.f;
@@ -388,6 +389,10 @@ __device__ __forceinline__ void gl_phi(int kind, int gen, bool real_side, float 
     //   D fake, G real : wants x small  -> relu(1 + x), (x + 1)^2 (ra) / x^2 (lsgan), softplus(x)
     const bool up = (real_side != (gen != 0));
     switch (kind) {
+        case GL_WGAN:                        // ops.py:757-759, 804-805: -mean(real) + mean(fake) ; G: -mean(fake)
+            *val = up ? -x : x;
+            *der = up ? -1.f : 1.f;
+            break;
         case GL_HINGE:
         case GL_RA_HINGE:
             if (kind == GL_HINGE && gen) {   // ops.py:832-833: -mean(fake)
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(AL_BLOCK) void gan_terms_kernel(int kind, int gen, 
                                                               const float* sums, double nr_g, double nf_g, float* tsums,
                                                               int nr, int nf) {
     __shared__ float sh[4];
-    const bool ra = kind >= GL_RA_LSGAN;
+    const bool ra = gl_relativistic(kind);
     const float mr = ra && nr_g > 0 ? (float)(sums[0] / nr_g) : 0.f;
     const float mf = ra && nf_g > 0 ? (float)(sums[1] / nf_g) : 0.f;
     float t[4] = {0.f, 0.f, 0.f, 0.f};
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(AL_BLOCK) void gan_grad_kernel(int kind, int gen, c
                                                              const float* sums, const float* tsums, double nr_g,
                                                              double nf_g, float flood, float* d_real, float* d_fake,
                                                              float* loss_out, int nr, int nf) {
-    const bool ra = kind >= GL_RA_LSGAN;
+    const bool ra = gl_relativistic(kind);
     const bool use_real = !(gen && !ra) && nr_g > 0;
     const float inv_r = use_real ? (float)(1.0 / nr_g) : 0.f, inv_f = (float)(1.0 / nf_g);
     const float mr = ra && nr_g > 0 ? (float)(sums[0] / nr_g) : 0.f;
@@ -492,6 +497,62 @@ __global__ __launch_bounds__(AL_BLOCK) void gan_grad_kernel(int kind, int gen, c
         gl_phi(kind, gen, false, fake[i] - mr, &v, &d);
         d_fake[i] = sgn * (d - cross_f) * inv_f;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// gradient penalty (BigGAN.py:717-742)
+// ------------------------------------------------------------------------------------------
+// interpolated = real + alpha_n * (other - real)                       (wgan-gp / wgan-lp: other = fake)
+//              = real + alpha_n * 0.5 * std(real) * other              (dragan: other = eps ~ U[0,1), sums != NULL)
+__global__ __launch_bounds__(AL_BLOCK) void gp_interpolate_kernel(const float* __restrict__ real,
+                                                                   const float* __restrict__ other,
+                                                                   const float* __restrict__ alpha,
+                                                                   const double* __restrict__ sums, double count,
+                                                                   float* __restrict__ out, int64_t per, int64_t total) {
+    float half_std = 0.f;
+    if (sums) {
+        const double m = sums[0] / count;
+        double var = sums[1] / count - m * m;
+        if (var < 0) var = 0;
+        half_std = 0.5f * sqrtf((float)var);
+    }
+    for (int64_t i = (int64_t)blockIdx.x * AL_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * AL_BLOCK) {
+        const float a = alpha[i / per], r = real[i];
+        out[i] = sums ? r + a * (half_std * other[i]) : r + a * (other[i] - r);
+    }
+}
+
+__global__ __launch_bounds__(AL_BLOCK) void gp_sumsq_kernel(const float* __restrict__ g, double* __restrict__ nsq,
+                                                             int64_t per) {
+    __shared__ float sh[4];
+    const float* gs = g + (int64_t)blockIdx.y * per;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * AL_BLOCK + threadIdx.x; i < per; i += (int64_t)gridDim.x * AL_BLOCK)
+        acc += gs[i] * gs[i];
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(nsq + blockIdx.y, (double)acc);
+}
+
+// per sample: n = ||g_n|| ; penalty (n-1)^2 (gp) or max(0,n-1)^2 (lp) ; coeff_n = ld * d(pen)/dn / count / n
+__global__ __launch_bounds__(AL_BLOCK) void gp_finish_kernel(double* ws, int N, double count, float ld, int lp,
+                                                              float* loss) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int n = threadIdx.x; n < N; n += AL_BLOCK) {
+        const float nrm = sqrtf((float)ws[n]);
+        float e = nrm - 1.f;
+        if (lp) e = fmaxf(e, 0.f);
+        acc += e * e;
+        ws[N + n] = nrm > 0.f ? (double)(ld * 2.f * e / nrm) / count : 0.0;
+    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) *loss = (float)((double)(ld * acc) / count);
+}
+
+__global__ __launch_bounds__(AL_BLOCK) void gp_scale_kernel(const float* __restrict__ g, const double* __restrict__ coeff,
+                                                             float* __restrict__ v, int64_t per, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * AL_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * AL_BLOCK)
+        v[i] = (float)coeff[i / per] * g[i];
 }
 
 // plain 'ortho' regulariser (utils.py:199-200): reg = A - I, loss = scale * l2_loss(reg), dA = scale * reg
@@ -654,7 +715,7 @@ int bg_gan_loss_means(const float* real, const float* fake, float* sums, int nr,
 
 int bg_gan_loss_terms(int kind, int generator, const float* real, const float* fake, const float* sums,
                       double n_real_global, double n_fake_global, float* tsums, int nr, int nf, void* stream) {
-    BG_REQUIRE(kind >= 0 && kind <= 5 && fake && sums && tsums && nf > 0 && nr >= 0 && (nr == 0 || real) &&
+    BG_REQUIRE(kind >= 0 && kind <= 6 && fake && sums && tsums && nf > 0 && nr >= 0 && (nr == 0 || real) &&
                    n_fake_global > 0, "bg_gan_loss_terms: bad argument");
     hipLaunchKernelGGL(gan_terms_kernel, dim3(1), dim3(AL_BLOCK), 0, as_stream(stream), kind, generator, real, fake,
                        sums, n_real_global, n_fake_global, tsums, nr, nf);
@@ -665,11 +726,45 @@ int bg_gan_loss_terms(int kind, int generator, const float* real, const float* f
 int bg_gan_loss_grad(int kind, int generator, const float* real, const float* fake, const float* sums,
                      const float* tsums, double n_real_global, double n_fake_global, float flood, float* d_real,
                      float* d_fake, float* loss_out, int nr, int nf, void* stream) {
-    BG_REQUIRE(kind >= 0 && kind <= 5 && fake && sums && tsums && d_fake && nf > 0 && nr >= 0 &&
+    BG_REQUIRE(kind >= 0 && kind <= 6 && fake && sums && tsums && d_fake && nf > 0 && nr >= 0 &&
                    (nr == 0 || (real && d_real)) && n_fake_global > 0, "bg_gan_loss_grad: bad argument");
     hipLaunchKernelGGL(gan_grad_kernel, dim3(1), dim3(AL_BLOCK), 0, as_stream(stream), kind, generator, real, fake,
                        sums, tsums, n_real_global, n_fake_global, flood, nr ? d_real : nullptr, d_fake, loss_out, nr,
                        nf);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_gp_interpolate(const float* real, const float* other, const float* alpha, const double* sums, double count,
+                      float* out, int N, int64_t per, void* stream) {
+    BG_REQUIRE(real && other && alpha && out && N > 0 && per > 0 && (!sums || count > 0), "bg_gp_interpolate: bad argument");
+    const int64_t total = (int64_t)N * per;
+    int64_t blocks = (total + AL_BLOCK - 1) / AL_BLOCK;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gp_interpolate_kernel, dim3((unsigned)blocks), dim3(AL_BLOCK), 0, as_stream(stream), real, other,
+                       alpha, sums, count, out, per, total);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_gp_penalty(const float* g, int N, int64_t per, double count_global, float ld, int lp, double* ws, float* loss,
+                  float* v, void* stream) {
+    BG_REQUIRE(g && ws && loss && v && N > 0 && per > 0 && count_global > 0, "bg_gp_penalty: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)N, st) != hipSuccess) {
+        set_error("bg_gp_penalty: memset failed");
+        return BG_ERR_LAUNCH;
+    }
+    int64_t gx = (per + AL_BLOCK * 8 - 1) / (AL_BLOCK * 8);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(gp_sumsq_kernel, dim3((unsigned)gx, (unsigned)N), dim3(AL_BLOCK), 0, st, g, ws, per);
+    BG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gp_finish_kernel, dim3(1), dim3(AL_BLOCK), 0, st, ws, N, count_global, ld, lp, loss);
+    BG_LAUNCH_CHECK();
+    const int64_t total = (int64_t)N * per;
+    int64_t blocks = (total + AL_BLOCK - 1) / AL_BLOCK;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gp_scale_kernel, dim3((unsigned)blocks), dim3(AL_BLOCK), 0, st, g, ws + N, v, per, total);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -644,6 +644,80 @@ __global__ __launch_bounds__(EW_BLOCK) void softmax_bwd_kernel(const float* __re
     }
 }
 
+// Second-order support (gradient penalty, BigGAN.py:717-742): derivative of the softmax tangent map
+//   pdot = p * (sdot - sum_j p_j sdot_j)   (the same arithmetic as softmax_bwd_kernel)
+// w.r.t. its two inputs, given g = dL/dpdot:
+//   dsdot = p * (g - u) ;  dp = g * (sdot - t) - u * sdot ;  t = sum p*sdot, u = sum g*p
+__global__ __launch_bounds__(EW_BLOCK) void softmax_tangent_bwd_kernel(const float* __restrict__ p,
+                                                                        const float* __restrict__ sdot,
+                                                                        const float* __restrict__ g,
+                                                                        float* __restrict__ dp,
+                                                                        float* __restrict__ dsdot, int64_t rows,
+                                                                        int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        float pv[SM_MAXPER], sv[SM_MAXPER], gv[SM_MAXPER];
+        float t = 0.f, u = 0.f;
+#pragma unroll
+        for (int j = 0; j < SM_MAXPER; ++j) {
+            const int c = lane + 64 * j;
+            pv[j] = c < cols ? p[r * cols + c] : 0.f;
+            sv[j] = c < cols ? sdot[r * cols + c] : 0.f;
+            gv[j] = c < cols ? g[r * cols + c] : 0.f;
+            t += pv[j] * sv[j];
+            u += gv[j] * pv[j];
+        }
+        t = wave_sum(t);
+        u = wave_sum(u);
+#pragma unroll
+        for (int j = 0; j < SM_MAXPER; ++j) {
+            const int c = lane + 64 * j;
+            if (c < cols) {
+                dsdot[r * cols + c] = pv[j] * (gv[j] - u);
+                dp[r * cols + c] = gv[j] * (sv[j] - t) - u * sv[j];
+            }
+        }
+    }
+}
+
+// tangent of the 2x2 max pool: y = t at the first maximum of x's window (the position maxpool2_bwd routes to)
+__global__ __launch_bounds__(EW_BLOCK) void maxpool2_gather_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                                    float* __restrict__ y, int N, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)N * Ho * Wo * C;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c = (int)(i % C);
+        int64_t q = i / C;
+        const int wo = (int)(q % Wo);
+        q /= Wo;
+        const int ho = (int)(q % Ho);
+        const int n = (int)(q / Ho);
+        const int64_t base = (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + c;
+        const int64_t o1 = C, o2 = (int64_t)W * C, o3 = (int64_t)W * C + C;
+        const float a = x[base], b = x[base + o1], c_ = x[base + o2], d = x[base + o3];
+        const float m = fmaxf(fmaxf(a, b), fmaxf(c_, d));
+        const int64_t sel = a == m ? 0 : (b == m ? o1 : (c_ == m ? o2 : o3));
+        y[i] = t[base + sel];
+    }
+}
+
+// d(alpha) of the PReLU tangent map ydot = xdot * prelu'(x): sum over rows of dy * xdot * [x < 0] (1/2 at x == 0)
+struct PreluTangentDalphaFn {
+    const float *x, *xdot, *dy;
+    int C;
+    template <int VEC>
+    __device__ __forceinline__ void operator()(int, int64_t r, int c, float (&acc)[1][VEC]) const {
+        float xv[VEC], tv[VEC], dv[VEC];
+        loadv<VEC>(x + r * C + c, xv);
+        loadv<VEC>(xdot + r * C + c, tv);
+        loadv<VEC>(dy + r * C + c, dv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[0][j] += dv[j] * tv[j] * (xv[j] < 0.f ? 1.f : (xv[j] == 0.f ? 0.5f : 0.f));
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // small elementwise family
 // ------------------------------------------------------------------------------------------
@@ -1233,6 +1307,42 @@ int bg_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, int
     }
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(ew_grid(rows * 64)), dim3(EW_BLOCK), 0, as_stream(stream), p, dp, ds,
                        rows, cols);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_softmax_tangent_bwd(const float* p, const float* sdot, const float* g, float* dp, float* dsdot, int64_t rows,
+                           int cols, void* stream) {
+    BG_REQUIRE(p && sdot && g && dp && dsdot && rows > 0 && cols > 0, "bg_softmax_tangent_bwd: bad argument");
+    if (cols > 64 * SM_MAXPER) {
+        set_error("bg_softmax_tangent_bwd: cols=%d > %d unsupported", cols, 64 * SM_MAXPER);
+        return BG_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(softmax_tangent_bwd_kernel, dim3(ew_grid(rows * 64)), dim3(EW_BLOCK), 0, as_stream(stream), p, sdot,
+                       g, dp, dsdot, rows, cols);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_maxpool2_gather(const float* x, const float* t, float* y, int N, int H, int W, int C, void* stream) {
+    BG_REQUIRE(x && t && y && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0,
+               "bg_maxpool2_gather: bad argument");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(maxpool2_gather_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), x, t, y, N, H,
+                       W, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_prelu_tangent_dalpha(const float* x, const float* xdot, const float* dy, float* dalpha, int64_t rows, int C,
+                            void* stream) {
+    BG_REQUIRE(x && xdot && dy && dalpha && rows > 0 && C > 0, "bg_prelu_tangent_dalpha: bad argument");
+    if (hipMemsetAsync(dalpha, 0, sizeof(float) * (size_t)C, as_stream(stream)) != hipSuccess) {
+        set_error("bg_prelu_tangent_dalpha: memset failed");
+        return BG_ERR_LAUNCH;
+    }
+    PreluTangentDalphaFn fn{x, xdot, dy, C};
+    launch_colreduce<1>(fn, dalpha, (int64_t)C, rows, 1, C, as_stream(stream));
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

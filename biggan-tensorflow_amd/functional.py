@@ -29,8 +29,24 @@ def is_variable(t):
     return getattr(t, "bg_name", None) is not None
 
 
+class _Mode:
+    # True while the input gradient of the gradient penalty is taken (BigGAN.py:731): backward passes then
+    # produce d/d(activation) only; nothing is written into the parameters' gradient slots
+    inputs_only = False
+
+
+class inputs_only_backward:
+    def __enter__(self):
+        self.prev, _Mode.inputs_only = _Mode.inputs_only, True
+
+    def __exit__(self, *exc):
+        _Mode.inputs_only = self.prev
+
+
 def emit_grad(var, producer):
     """Deliver d(loss)/d(var).  ``producer(out)`` must WRITE the gradient into ``out``."""
+    if _Mode.inputs_only:
+        return
     slot = getattr(var, "bg_grad", None)
     if slot is None:                       # stand-alone variable (not packed into an arena)
         g = torch.empty(var.shape, dtype=torch.float32, device=var.device)
@@ -52,7 +68,7 @@ def emit_grad(var, producer):
 def param_grad(t, needed, producer):
     """Gradient for an input that may be a store variable (side-effect delivery, returns None)
     or an ordinary autograd tensor (returned)."""
-    if not needed:
+    if not needed or _Mode.inputs_only:
         return None
     if is_variable(t):
         emit_grad(t, producer)
@@ -758,6 +774,165 @@ class ScaleAddFn(Function):
 
 
 # ------------------------------------------------------------------------------------------
+# tangent (forward-mode) maps of the discriminator's non-linear ops, each with its own backward: the gradient
+# penalty's parameter gradient is the gradient of a directional derivative of D (include/biggan_hip.h, "Gradient
+# penalty").  Linear ops (conv, dense, pooling sums, residual adds) are their own tangent maps.
+# ------------------------------------------------------------------------------------------
+class PReluTangentFn(Function):
+    """ydot = xdot * prelu'(x; alpha)."""
+
+    @staticmethod
+    def forward(ctx, xdot, x, alpha):
+        xdot, x = _c(xdot), _c(x)
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        check(lib().bg_prelu_bwd(f32(x), f32(xdot), f32(alpha), f32(y), None, x.numel() // C, C, stream()))
+        ctx.xdot, ctx.x, ctx.alpha = xdot, x, alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        xdot, x, alpha = ctx.xdot, ctx.x, ctx.alpha
+        C = x.shape[-1]
+        rows = x.numel() // C
+        L = lib()
+        dxdot = None
+        if ctx.needs_input_grad[0]:
+            dxdot = torch.empty_like(x)
+            check(L.bg_prelu_bwd(f32(x), f32(dy), f32(alpha), f32(dxdot), None, rows, C, stream()))
+
+        def prod(out):
+            check(L.bg_prelu_tangent_dalpha(f32(x), f32(xdot), f32(dy), f32(out), rows, C, stream()))
+        da = param_grad(alpha, ctx.needs_input_grad[2], prod)
+        ctx.xdot = ctx.x = None
+        return dxdot, None, da          # piecewise linear: no gradient reaches x through the slope
+
+
+class MaxPool2TangentFn(Function):
+    """ydot = xdot at the arg-max of x's 2x2 window."""
+
+    @staticmethod
+    def forward(ctx, xdot, x):
+        xdot, x = _c(xdot), _c(x)
+        N, H, W_, C = x.shape
+        y = torch.empty((N, H // 2, W_ // 2, C), dtype=torch.float32, device=x.device)
+        check(lib().bg_maxpool2_gather(f32(x), f32(xdot), f32(y), N, H, W_, C, stream()))
+        ctx.x = x
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        x = ctx.x
+        N, H, W_, C = x.shape
+        d = torch.empty_like(x)
+        check(lib().bg_maxpool2_bwd(f32(x), f32(dy), f32(d), N, H, W_, C, stream()))
+        ctx.x = None
+        return d, None
+
+
+class BmmFn(Function):
+    """Batched a @ b or a @ b^T on [B, M, K] x [B, K, N] (resp. [B, N, K]) with gradients to both operands."""
+
+    @staticmethod
+    def forward(ctx, a, b, trans_b):
+        a, b = _c(a), _c(b)
+        B, M, K = a.shape
+        N = b.shape[1] if trans_b else b.shape[2]
+        y = torch.empty((B, M, N), dtype=torch.float32, device=a.device)
+        ldb = K if trans_b else N
+        gemm(a, b, y, M, N, K, K, ldb, N, transB=trans_b, batch=B, sA=M * K, sB=b.shape[1] * b.shape[2], sC=M * N)
+        ctx.a, ctx.b, ctx.trans_b = a, b, trans_b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        a, b, tb = ctx.a, ctx.b, ctx.trans_b
+        B, M, K = a.shape
+        N = dy.shape[2]
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty_like(a)        # dy @ b (trans_b) or dy @ b^T
+            gemm(dy, b, da, M, K, N, N, K if tb else N, K, transB=not tb, batch=B, sA=M * N, sB=b.shape[1] * b.shape[2],
+                 sC=M * K)
+        if ctx.needs_input_grad[1]:
+            db = torch.empty_like(b)
+            if tb:                          # b [B,N,K]: dy^T @ a
+                gemm(dy, a, db, N, K, M, N, K, K, transA=True, batch=B, sA=M * N, sB=M * K, sC=N * K)
+            else:                           # b [B,K,N]: a^T @ dy
+                gemm(a, dy, db, K, N, M, K, N, N, transA=True, batch=B, sA=M * K, sB=M * N, sC=K * N)
+        ctx.a = ctx.b = None
+        return da, db, None
+
+
+class SoftmaxFn(Function):
+    """Row softmax over the last axis with P kept (the materialised attention of the gradient-penalty passes)."""
+
+    @staticmethod
+    def forward(ctx, s_):
+        s_ = _c(s_)
+        p = torch.empty_like(s_)
+        cols = s_.shape[-1]
+        check(lib().bg_softmax_fwd(f32(s_), f32(p), s_.numel() // cols, cols, stream()))
+        ctx.p = p
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        dp = _c(dp)
+        p = ctx.p
+        cols = p.shape[-1]
+        ds = torch.empty_like(p)
+        check(lib().bg_softmax_bwd(f32(p), f32(dp), f32(ds), p.numel() // cols, cols, stream()))
+        ctx.p = None
+        return ds
+
+
+class SoftmaxTangentFn(Function):
+    """pdot = p * (sdot - sum_j p_j sdot_j), differentiable w.r.t. both p and sdot."""
+
+    @staticmethod
+    def forward(ctx, p, sdot):
+        p, sdot = _c(p), _c(sdot)
+        cols = p.shape[-1]
+        y = torch.empty_like(p)
+        check(lib().bg_softmax_bwd(f32(p), f32(sdot), f32(y), p.numel() // cols, cols, stream()))
+        ctx.p, ctx.sdot = p, sdot
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        p, sdot = ctx.p, ctx.sdot
+        cols = p.shape[-1]
+        dp, dsdot = torch.empty_like(p), torch.empty_like(p)
+        check(lib().bg_softmax_tangent_bwd(f32(p), f32(sdot), f32(g), f32(dp), f32(dsdot), p.numel() // cols, cols,
+                                           stream()))
+        ctx.p = ctx.sdot = None
+        return dp, dsdot
+
+
+class GpSurrogateFn(Function):
+    """Carries the gradient penalty's VALUE forward and, backward, hands a unit gradient to the directional
+    derivatives ``fdot`` whose parameter gradient is the penalty's (see "Gradient penalty" in the header)."""
+
+    @staticmethod
+    def forward(ctx, fdot, value):
+        ctx.shape = fdot.shape
+        return value.detach().clone()
+
+    @staticmethod
+    def backward(ctx, dy):
+        ones = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        ones.fill_(1.0)
+        g = torch.empty_like(ones)
+        check(lib().bg_scale_dev(f32(ones), f32(_c(dy).reshape(-1)[:1]), f32(g), ones.numel(), stream()))
+        return g, None
+
+
+# ------------------------------------------------------------------------------------------
 # DiffAugment
 # ------------------------------------------------------------------------------------------
 class DiffAugmentFn(Function):
@@ -852,7 +1027,8 @@ class HingeGLossFn(Function):
         return df, None, None, None
 
 
-GAN_LOSS_KINDS = {"hinge": 0, "lsgan": 1, "gan": 2, "ra-lsgan": 3, "ra-gan": 4, "ra-hinge": 5}
+GAN_LOSS_KINDS = {"hinge": 0, "lsgan": 1, "gan": 2, "ra-lsgan": 3, "ra-gan": 4, "ra-hinge": 5,
+                  "dragan": 2, "ra-dragan": 4, "wgan-gp": 6, "wgan-lp": 6}          # ops.py:757,771,775 ('wgan' substring)
 
 
 class GanLossFn(Function):

@@ -77,10 +77,22 @@ class BigGAN(GANBase):
         self.gan_type = args.gan_type
         self.d_loss_func = args.d_loss_func if args.d_loss_func else self.gan_type     # BigGAN.py:127-128
         if self.gan_type not in Fn.GAN_LOSS_KINDS or self.d_loss_func not in Fn.GAN_LOSS_KINDS:
-            raise NotImplementedError("--gan_type / --d_loss_func %s / %s: the gradient-penalty losses (wgan-gp, wgan-lp, "
-                                      "dragan, ra-dragan) need double backward and are not implemented; available: %s"
-                                      % (self.gan_type, self.d_loss_func, ", ".join(sorted(Fn.GAN_LOSS_KINDS))))
+            raise ValueError("--gan_type / --d_loss_func %s / %s: available: %s"
+                             % (self.gan_type, self.d_loss_func, ", ".join(sorted(Fn.GAN_LOSS_KINDS))))
         self.relativistic = self.gan_type.startswith('ra-')
+        if 'wgan' in self.d_loss_func:                                                 # BigGAN.py:130-138
+            self.gradient_penalty_type = self.gan_type
+        elif 'dragan' in self.d_loss_func:
+            self.gradient_penalty_type = 'dragan'
+        else:
+            self.gradient_penalty_type = None
+        self.use_gradient_penalty = bool(self.gradient_penalty_type)
+        if self.use_gradient_penalty and self.gradient_penalty_type not in ('wgan-gp', 'wgan-lp', 'dragan'):
+            raise ValueError("gradient penalty type %r (BigGAN.py:736-740 knows wgan-gp, wgan-lp, dragan)"
+                             % self.gradient_penalty_type)
+        if self.use_gradient_penalty and args.bn_in_d:
+            raise NotImplementedError("gradient penalty with --bn_in_d (the tangent pass of batch norm)")
+        self.ld = args.ld
 
         self.activation = args.activation                                              # BigGAN.py:71-83
         if self.activation == 'relu':
@@ -501,7 +513,70 @@ class BigGAN(GANBase):
             self._cls_loss_fn = cls_loss_fn(self.cls_loss_type, w)                     # BigGAN.py:851-852
         return self._cls_loss_fn
 
-    def d_forward(self, real, z=None, draws_real=None, draws_fake=None, labels=None, cls_z=None):
+    def gp_draws(self, B):
+        """The random inputs of one gradient_penalty() call (BigGAN.py:719, 726, 729): eps ~ U[0,1) with the
+        batch's shape (dragan only), alpha ~ U[0,1) per sample, and one set of DiffAugment draws."""
+        from .DiffAugment import draw
+        S_ = self.img_size
+        out = {"alpha": torch.rand(B, dtype=torch.float32, device=self.device, generator=self.gen),
+               "aug": draw(B, S_, self.device, self.gen) if self.da_policy else None}
+        if self.gradient_penalty_type == 'dragan':
+            out["eps"] = torch.rand(B, S_, S_, self.c_dim, dtype=torch.float32, device=self.device, generator=self.gen)
+        return out
+
+    def gradient_penalty(self, real, fake, draws=None):
+        """BigGAN.py:717-742.  GP = ld * mean phi(||d D(aug(x^))/d x^||) on x^ between the real batch and the fake
+        batch (wgan-gp / wgan-lp) or a perturbed real batch (dragan).  Three discriminator passes on x^:
+        (1) forward + an inputs-only backward give g = dD/dx^, its norms, the penalty's value and the constant
+        direction v = ld * phi'(||g||)/count * g/||g||;  (2) a forward-mode pass carries (x^, v) through DiffAugment
+        and D as a ``Dual`` and yields the directional derivatives fdot = <g(theta), v>;  (3) the ordinary backward
+        of d_loss differentiates fdot w.r.t. the parameters, which IS d GP/d theta (v held constant)."""
+        from .ops import Dual
+        L = Fn.lib()
+        B = real.shape[0]
+        per = real.numel() // B
+        if draws is None:
+            draws = self.gp_draws(B)
+        real = real.contiguous()
+        xhat = torch.empty_like(real)
+        if self.gradient_penalty_type == 'dragan':
+            sums = torch.zeros(2, dtype=torch.float64, device=self.device)
+            Fn.check(L.bg_bn_stats(Fn.f32(real), Fn.hip.ptr(sums), real.numel(), 1, Fn.stream()))
+            Fn.check(L.bg_gp_interpolate(Fn.f32(real), Fn.f32(draws["eps"].contiguous()), Fn.f32(draws["alpha"]),
+                                         Fn.hip.ptr(sums), float(real.numel()), Fn.f32(xhat), B, per, Fn.stream()))
+        else:
+            Fn.check(L.bg_gp_interpolate(Fn.f32(real), Fn.f32(fake.detach().contiguous()), Fn.f32(draws["alpha"]), None,
+                                         0.0, Fn.f32(xhat), B, per, Fn.stream()))
+        aug = draws.get("aug")
+        # (1) g = d sum(D(aug(x^))) / d x^
+        xg = xhat.detach().requires_grad_(True)
+        logit = self.discriminator(DiffAugment(xg, policy=self.da_policy, draws=aug), reuse=True)["real"]
+        seed = torch.empty_like(logit)
+        seed.fill_(1.0)
+        with Fn.inputs_only_backward():
+            g, = torch.autograd.grad(logit, xg, grad_outputs=seed)
+        g = g.contiguous()
+        ws = torch.empty(2 * B, dtype=torch.float64, device=self.device)
+        value = torch.empty(1, dtype=torch.float32, device=self.device)
+        v = torch.empty_like(g)
+        Fn.check(L.bg_gp_penalty(Fn.f32(g), B, per, float(B * self.world), float(self.ld),
+                                 int(self.gradient_penalty_type == 'wgan-lp'), Fn.hip.ptr(ws), Fn.f32(value), Fn.f32(v),
+                                 Fn.stream()))
+        red = self._reduce_fn()
+        if red is not None:
+            red(value)
+        # (2) forward-mode pass; the tangent of DiffAugment is DiffAugment without the brightness offset
+        if self.da_policy:
+            lin = dict(aug)
+            lin["u_b"] = torch.full_like(aug["u_b"], 0.5)
+            dual = Dual(DiffAugment(xhat, policy=self.da_policy, draws=aug),
+                        DiffAugment(v, policy=self.da_policy, draws=lin))
+        else:
+            dual = Dual(xhat, v)
+        fdot = self.discriminator(dual, reuse=True)["real"].t
+        return Fn.GpSurrogateFn.apply(fdot, value)
+
+    def d_forward(self, real, z=None, draws_real=None, draws_fake=None, labels=None, cls_z=None, gp_draws=None):
         """BigGAN.py:806-808, 856-883: D(aug(real)), D(aug(G(z))), hinge + flood (+ the label loss on the
         real half when n_labels > 0, BigGAN.py:853).  G runs without a backward graph (d_loss is minimised
         over d_vars only); real and fake go through D as one batch."""
@@ -527,6 +602,9 @@ class BigGAN(GANBase):
             real_logits, fake_logits = logits[:B], logits[B:]
         d_loss = discriminator_loss(self.d_loss_func, real=real_logits, fake=fake_logits, flood_level=self.d_flood)
         out = {"real_logits": real_logits, "fake_logits": fake_logits, "fake": fake}
+        if self.use_gradient_penalty:                                                  # BigGAN.py:867-868, 880
+            out["gp"] = self.gradient_penalty(real, fake, gp_draws)
+            d_loss = Fn.AddFn.apply(d_loss, out["gp"])
         if self.acgan:
             if labels is None:
                 raise ValueError("n_labels > 0: d_forward needs the labels of the real batch")
@@ -545,7 +623,7 @@ class BigGAN(GANBase):
         return v
 
     def d_step(self, real, z=None, draws_real=None, draws_fake=None, apply=True, labels=None, cls_z=None,
-               defer=False):
+               defer=False, gp_draws=None):
         """One run of d_ops (utils.py:252-320): with --virtual_batches k, gradients of k forward/backward
         passes (each on its own real batch / z / draws; lists of k are accepted) are accumulated and
         applied once, scaled 1/k; reported losses are means over the k passes."""
@@ -554,7 +632,8 @@ class BigGAN(GANBase):
         outs = []
         for k in range(vb):
             out = self.d_forward(*[self._per_virtual_batch(k, a) for a in (real, z, draws_real, draws_fake, labels)],
-                                 cls_z=cls_z)                                        # one feed_dict for all k
+                                 cls_z=cls_z,                                        # one feed_dict for all k
+                                 gp_draws=self._per_virtual_batch(k, gp_draws))
             out["d_loss"].backward()
             self._sn_backward("discriminator")
             outs.append(out)
@@ -569,7 +648,7 @@ class BigGAN(GANBase):
             self._allreduce_grads(self.d_arena)
             if apply:
                 self._adam(self.d_arena, self.d_learning_rate, with_ema=False, grad_scale=1.0 / vb)
-        return self._mean_losses(outs, ("d_loss", "d_cls_loss"))
+        return self._mean_losses(outs, ("d_loss", "d_cls_loss", "gp"))
 
     def _finish_d(self):
         pending = getattr(self, "_pending_d", None)

@@ -69,6 +69,35 @@ def _is_meta(x):
     return x.device.type == "meta"
 
 
+class Dual:
+    """A (primal, tangent) pair travelling through the discriminator: the forward-mode pass of the gradient
+    penalty (BigGAN.py:717-742; see "Gradient penalty" in include/biggan_hip.h).  Operators that receive a Dual
+    apply themselves to ``p`` and their tangent map to ``t``; linear operators are their own tangent map (without
+    the bias)."""
+
+    def __init__(self, p, t):
+        assert p.shape == t.shape, (p.shape, t.shape)
+        self.p, self.t = p, t
+
+    shape = property(lambda self: self.p.shape)
+    device = property(lambda self: self.p.device)
+    requires_grad = property(lambda self: self.p.requires_grad or self.t.requires_grad)
+    is_cuda = property(lambda self: self.p.is_cuda)
+
+    def dim(self):
+        return self.p.dim()
+
+    def reshape(self, *shape):
+        return Dual(self.p.reshape(*shape), self.t.reshape(*shape))
+
+    def __getitem__(self, idx):
+        return Dual(self.p[idx], self.t[idx])
+
+
+def _is_dual(x):
+    return isinstance(x, Dual)
+
+
 def _meta(shape):
     return torch.empty(tuple(int(s) for s in shape), device="meta")
 
@@ -148,6 +177,9 @@ def conv(x, channels, opt, kernel=4, stride=2, pad=0, dilation=1, use_bias=True,
                 bias = get_variable("bias", [channels], initializer=S.constant_initializer(0.0))
         if _is_meta(x):
             return _meta((N, Ho, Wo, channels))
+        if _is_dual(x):
+            return Dual(Fn.Conv2dFn.apply(x.p, wk, bias, stride, pad_lo, Ho, Wo, pad_mode),
+                        Fn.Conv2dFn.apply(x.t, wk, None, stride, pad_lo, Ho, Wo, pad_mode))
         return Fn.Conv2dFn.apply(x, wk, bias, stride, pad_lo, Ho, Wo, pad_mode)
 
 
@@ -192,11 +224,15 @@ def fully_connected(x, units, opt, use_bias=True, lrmul=1.0, scope='fully_0'):
         wk = spectral_norm(w, _shape_only=_is_meta(x)) if opt.get("conv", {}).get("sn", True) else w
         if _is_meta(x):
             return _meta((x.shape[0], units))
+        if _is_dual(x):
+            return Dual(Fn.DenseFn.apply(x.p, wk, bias), Fn.DenseFn.apply(x.t, wk, None))
         return Fn.DenseFn.apply(x, wk, bias)
 
 
 def flatten(x):
     """ops.py:177-178.  Keeps column slices as views (no copy)."""
+    if _is_dual(x):
+        return Dual(flatten(x.p), flatten(x.t))
     if x.dim() == 2:
         return x
     if x.dim() == 4 and x.shape[1] == 1 and x.shape[2] == 1:
@@ -215,11 +251,15 @@ def hw_flatten(x):
 def _add(a, b):
     if _is_meta(a):
         return _meta(a.shape)
+    if _is_dual(a):
+        return Dual(Fn.AddFn.apply(a.p, b.p), Fn.AddFn.apply(a.t, b.t))
     return Fn.AddFn.apply(a, b)
 
 
 def _fork(x, n=2):
     """A tensor consumed by n branches: the branch gradients are summed by a HIP kernel."""
+    if _is_dual(x):
+        return tuple(Dual(a, b) for a, b in zip(_fork(x.p, n), _fork(x.t, n)))
     if _is_meta(x) or not (torch.is_grad_enabled() and x.requires_grad):
         return (x,) * n
     return Fn.ForkFn.apply(x, n)
@@ -463,13 +503,33 @@ def self_attention_2(x, channels, opt, scope='self_attention'):
         gamma = get_variable("gamma", [1], initializer=S.constant_initializer(0.0))
         if _is_meta(x):
             o = _meta((x.shape[0], x.shape[1], x.shape[2], channels // 2))
+        elif _is_dual(x):
+            o = _attention_dual(hw_flatten(g), hw_flatten(f), hw_flatten(h))
+            o = o.reshape(x.shape[0], x.shape[1], x.shape[2], channels // 2)
         else:
             o = Fn.AttentionFn.apply(hw_flatten(g), hw_flatten(f), hw_flatten(h))     # softmax(g f^T) h
             o = o.reshape(x.shape[0], x.shape[1], x.shape[2], channels // 2)
         o = conv(o, channels, kernel=1, stride=1, opt=opt, scope='attn_conv', use_bias=use_bias)
         if _is_meta(x):
             return _meta(x.shape)
+        if _is_dual(x):
+            return Dual(Fn.ScaleAddFn.apply(o.p, gamma, x.p), Fn.ScaleAddFn.apply(o.t, gamma, x.t))
         return Fn.ScaleAddFn.apply(o, gamma, x)                                          # gamma * o + x
+
+
+def _attention_dual(q, k, v):
+    """softmax(q k^T) v and its tangent with the probabilities materialised (BmmFn / SoftmaxFn / SoftmaxTangentFn):
+    sdot = qdot k^T + q kdot^T ; pdot = p * (sdot - <p, sdot>) ; odot = pdot v + p vdot."""
+    q1, q2 = _fork(q.p)
+    k1, k2 = _fork(k.p)
+    v1, v2 = _fork(v.p)
+    p = Fn.SoftmaxFn.apply(Fn.BmmFn.apply(q1, k1, True))
+    p1, p2, p3 = _fork(p, 3)
+    o = Fn.BmmFn.apply(p1, v1, False)
+    sdot = Fn.AddFn.apply(Fn.BmmFn.apply(q.t, k2, True), Fn.BmmFn.apply(q2, k.t, True))
+    pdot = Fn.SoftmaxTangentFn.apply(p2, sdot)
+    odot = Fn.AddFn.apply(Fn.BmmFn.apply(pdot, v2, False), Fn.BmmFn.apply(p3, v.t, False))
+    return Dual(o, odot)
 
 
 ##################################################################################
@@ -483,6 +543,8 @@ def global_sum_pooling(x):
     """ops.py:503-506."""
     if _is_meta(x):
         return _meta((x.shape[0], x.shape[-1]))
+    if _is_dual(x):
+        return Dual(Fn.SumPoolFn.apply(x.p), Fn.SumPoolFn.apply(x.t))
     return Fn.SumPoolFn.apply(x)
 
 
@@ -492,6 +554,9 @@ def max_pooling(x):
         raise NotImplementedError("max_pooling on odd spatial sizes")
     if _is_meta(x):
         return _meta((x.shape[0], x.shape[1] // 2, x.shape[2] // 2, x.shape[3]))
+    if _is_dual(x):
+        p_pool, p_sel = _fork(x.p)
+        return Dual(Fn.MaxPool2Fn.apply(p_pool), Fn.MaxPool2TangentFn.apply(x.t, p_sel))
     return Fn.MaxPool2Fn.apply(x)
 
 
@@ -501,6 +566,8 @@ def avg_pooling(x):
         raise NotImplementedError("avg_pooling on odd spatial sizes")
     if _is_meta(x):
         return _meta((x.shape[0], x.shape[1] // 2, x.shape[2] // 2, x.shape[3]))
+    if _is_dual(x):
+        return Dual(Fn.AvgPool2Fn.apply(x.p), Fn.AvgPool2Fn.apply(x.t))
     return Fn.AvgPool2Fn.apply(x)
 
 
@@ -526,18 +593,25 @@ def _constant_alpha(C, value, device):
     return _const_alpha[key]
 
 
+def _prelu_apply(x, alphas):
+    if _is_dual(x):
+        p_act, p_mask = _fork(x.p)          # the primal feeds its own activation and the tangent's slope mask
+        return Dual(Fn.PReluFn.apply(p_act, alphas), Fn.PReluTangentFn.apply(x.t, p_mask, alphas))
+    return Fn.PReluFn.apply(x, alphas)
+
+
 def lrelu(x, alpha=0.2):
     """ops.py:525-526."""
     if _is_meta(x):
         return _meta(x.shape)
-    return Fn.PReluFn.apply(x, _constant_alpha(x.shape[-1], alpha, x.device))
+    return _prelu_apply(x, _constant_alpha(x.shape[-1], alpha, x.device))
 
 
 def relu(x):
     """ops.py:529-530."""
     if _is_meta(x):
         return _meta(x.shape)
-    return Fn.PReluFn.apply(x, _constant_alpha(x.shape[-1], 0.0, x.device))
+    return _prelu_apply(x, _constant_alpha(x.shape[-1], 0.0, x.device))
 
 
 def prelu(x, scope=None, init_val=0.0):
@@ -546,7 +620,7 @@ def prelu(x, scope=None, init_val=0.0):
         alphas = get_variable('alpha', x.shape[-1], initializer=S.constant_initializer(init_val))
         if _is_meta(x):
             return _meta(x.shape)
-        return Fn.PReluFn.apply(x, alphas)
+        return _prelu_apply(x, alphas)
 
 
 def tanh(x):
@@ -570,6 +644,8 @@ def _bn_type(opt, scope):
 
 def bn(x, opt={}, scope='batch_norm'):
     """ops.py:546-561."""
+    if _is_dual(x):
+        raise NotImplementedError("gradient penalty with --bn_in_d: the tangent pass of batch norm is not implemented")
     type, scope = _bn_type(opt, scope)
     if type == 'bn' or type == 'batch_norm':
         return batch_norm(x, opt=opt, scope=scope)
@@ -763,8 +839,7 @@ def discriminator_loss(loss_func, real, fake, flood_level=0):
         return Fn.HingeDLossFn.apply(real, fake, flood_level, _run.reduce_fn, _run.world)
     if loss_func in Fn.GAN_LOSS_KINDS:
         return Fn.GanLossFn.apply(real, fake, Fn.GAN_LOSS_KINDS[loss_func], 0, flood_level, _run.reduce_fn, _run.world)
-    raise NotImplementedError("discriminator_loss('%s'): gradient-penalty losses (wgan-gp, wgan-lp, dragan, "
-                              "ra-dragan) need double backward and are not implemented" % loss_func)
+    raise ValueError("discriminator_loss: unknown loss '%s'" % loss_func)
 
 
 def generator_loss(loss_func, fake, real, flood_level=0):

@@ -300,8 +300,8 @@ int bg_hinge_g_sums(const float* fake, float* sums, int n, void* stream);
 int bg_hinge_g_grad(const float* sums, double n_global, float flood, float* d_fake, float* loss_out,
                     int n, void* stream);
 
-/* General non-penalty GAN losses (ops.py:753-840): kind 0 hinge, 1 lsgan, 2 gan, 3 ra-lsgan, 4 ra-gan,
- * 5 ra-hinge; generator = 0 for discriminator_loss, 1 for generator_loss.  Three steps so that data-parallel
+/* General GAN losses (ops.py:753-840): kind 0 hinge, 1 lsgan, 2 gan (also 'dragan'), 3 ra-lsgan, 4 ra-gan (also
+ * 'ra-dragan'), 5 ra-hinge, 6 wgan (wgan-gp / wgan-lp); generator = 0 for discriminator_loss, 1 for generator_loss.  Three steps so that data-parallel
  * ranks can exchange the sums in between:  bg_gan_loss_means -> sums = {sum real, sum fake};
  * bg_gan_loss_terms (given the GLOBAL sums / counts) -> tsums = {sum phi_r, sum phi_f, sum phi_r', sum phi_f'};
  * bg_gan_loss_grad (given the GLOBAL tsums) -> loss (flooded), d_real, d_fake (incl. the coupling through the
@@ -312,6 +312,36 @@ int bg_gan_loss_terms(int kind, int generator, const float* real, const float* f
 int bg_gan_loss_grad(int kind, int generator, const float* real, const float* fake, const float* sums,
                      const float* tsums, double n_real_global, double n_fake_global, float flood, float* d_real,
                      float* d_fake, float* loss_out, int nr, int nf, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Gradient penalty (BigGAN.py:717-742) and the second-order pieces it needs.
+ *   GP = ld * mean_n phi(||g_n||),  g = d sum(D(aug(x^)))/d x^,  phi = (n-1)^2 (wgan-gp, dragan) or max(0,n-1)^2 (wgan-lp).
+ *   Its parameter gradient is taken as the gradient of the directional derivative of D along the constant
+ *   direction v_n = ld * phi'(||g_n||) / count * g_n / ||g_n||  (d GP/d theta = d <g(theta), v>/d theta), i.e. by
+ *   differentiating a forward-mode (tangent) pass of the discriminator; the entries below are the tangent maps that
+ *   are not already linear kernels of this library, and their derivatives.
+ * bg_gp_interpolate: x^ = real + alpha_n (other - real)           (sums == NULL; other = fake: BigGAN.py:726-727)
+ *                    x^ = real + alpha_n * 0.5 * std(real) * other (sums = {sum real, sum real^2} in fp64 from
+ *                         bg_bn_stats with C = 1, count = numel: BigGAN.py:719-724, other = eps ~ U[0,1))
+ * bg_gp_penalty: g [N, per] -> *loss = ld * sum_n phi(||g_n||) / count_global (this rank's share of the mean),
+ *                v = the direction above; ws: 2*N doubles of scratch; lp = 1 selects wgan-lp.
+ * bg_maxpool2_gather: tangent of the 2x2 max pool, y = t at the first maximum of x's window (its transpose is
+ *                bg_maxpool2_bwd).
+ * bg_prelu_tangent_dalpha: the PReLU tangent is ydot = xdot * prelu'(x) (computed by bg_prelu_bwd with dy := xdot);
+ *                its derivative w.r.t. alpha is dalpha[c] = sum_rows dy * xdot * [x < 0]  (1/2 at x == 0).
+ * bg_softmax_tangent_bwd: the softmax tangent is pdot = p * (sdot - sum p sdot) (computed by bg_softmax_bwd with
+ *                dp := sdot); given g = dL/dpdot:  dsdot = p * (g - u), dp = g * (sdot - t) - u * sdot,
+ *                t = sum p sdot, u = sum g p (row sums).
+ * ------------------------------------------------------------------------------------------ */
+int bg_gp_interpolate(const float* real, const float* other, const float* alpha, const double* sums, double count,
+                      float* out, int N, int64_t per, void* stream);
+int bg_gp_penalty(const float* g, int N, int64_t per, double count_global, float ld, int lp, double* ws, float* loss,
+                  float* v, void* stream);
+int bg_maxpool2_gather(const float* x, const float* t, float* y, int N, int H, int W, int C, void* stream);
+int bg_prelu_tangent_dalpha(const float* x, const float* xdot, const float* dy, float* dalpha, int64_t rows, int C,
+                            void* stream);
+int bg_softmax_tangent_bwd(const float* p, const float* sdot, const float* g, float* dp, float* dsdot, int64_t rows,
+                           int cols, void* stream);
 
 /* Class-label loss of the conditional model (utils.py:366-369, BigGAN.py:853,894), 'logistic' type:
  *   loss = scale * sum_{b,j} sigmoid_cross_entropy_with_logits(truth, logits)[b,j] * weights[j]

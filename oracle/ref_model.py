@@ -49,6 +49,7 @@ class Config:
         self.g_grow_factor = 2.0
         self.d_grow_factor = 2.0
         self.gan_type = "hinge"
+        self.ld = 10.0                        # main.py:64
         self.d_flood = 0.1
         self.g_flood = 0.05
         self.da_policy = "full"
@@ -302,7 +303,29 @@ class Trainer:
     def _t(self, a):
         return torch.tensor(np.asarray(a), dtype=self.dtype)
 
-    def d_forward(self, real, z, aug_real, aug_fake, labels=None, cls_z=None):
+    def gradient_penalty_type(self):
+        """BigGAN.py:130-135 (d_loss_func == gan_type here)."""
+        gt = self.cfg.gan_type
+        return gt if "wgan" in gt else ("dragan" if "dragan" in gt else None)
+
+    def gradient_penalty(self, real, fake, gp):
+        """BigGAN.py:717-742 with the random inputs given: gp = {"eps" (dragan), "alpha" [B], "aug" draws}."""
+        cfg, vs = self.cfg, self.vs
+        kind = self.gradient_penalty_type()
+        B = real.shape[0]
+        if kind == "dragan":
+            x_std = torch.sqrt(((real - real.mean()) ** 2).mean())            # tf.nn.moments over all axes
+            fake = real + 0.5 * x_std * self._t(gp["eps"])
+        alpha = self._t(gp["alpha"]).reshape(B, 1, 1, 1)
+        interpolated = (real + alpha * (fake - real)).detach().requires_grad_(True)
+        logit = discriminator(vs, cfg, R.diffaugment(interpolated, gp["aug"], cfg.da_policy))["real"]
+        grad, = torch.autograd.grad(logit.sum(), interpolated, create_graph=True)    # tf.gradients(logit, x)[0]
+        grad_norm = torch.sqrt((grad.reshape(B, -1) ** 2).sum(dim=1))
+        if kind == "wgan-lp":
+            return cfg.ld * (torch.clamp(grad_norm - 1.0, min=0.0) ** 2).mean()
+        return cfg.ld * ((grad_norm - 1.0) ** 2).mean()
+
+    def d_forward(self, real, z, aug_real, aug_fake, labels=None, cls_z=None, gp=None):
         cfg, vs = self.cfg, self.vs
         vs.reg_losses = []
         vs.state_updates.clear()
@@ -312,13 +335,17 @@ class Trainer:
         fake = generator(vs, cfg, self._t(z), cz, True)                             # :883
         d_fake = discriminator(vs, cfg, R.diffaugment(fake, aug_fake, cfg.da_policy))   # :857
         d_loss = R.discriminator_loss(cfg.gan_type, d_real["real"], d_fake["real"], cfg.d_flood)  # :879
+        gp_val = None
+        if self.gradient_penalty_type():                                            # :867-868, 880
+            gp_val = self.gradient_penalty(self._t(real), fake.detach(), gp)
+            d_loss = d_loss + gp_val
         d_cls = None
         if cfg.n_labels:
             w = torch.ones(cfg.n_labels, dtype=self.dtype)
             d_cls = cfg.d_cls_loss_weight * R.cls_loss_logistic(self._t(labels), d_real["cls"], w)  # :853
             d_loss = d_loss + d_cls
         return {"d_loss": d_loss, "real_logits": d_real["real"], "fake_logits": d_fake["real"],
-                "fake": fake, "d_cls_loss": d_cls}
+                "fake": fake, "d_cls_loss": d_cls, "gp": gp_val}
 
     def g_forward(self, z, aug_fake, cls_z=None, real=None, aug_real=None):
         cfg, vs = self.cfg, self.vs
@@ -364,8 +391,8 @@ class Trainer:
             vs.commit()
         return img
 
-    def d_step(self, real, z, aug_real, aug_fake, labels=None, cls_z=None, apply=True):
-        out = self.d_forward(real, z, aug_real, aug_fake, labels, cls_z)
+    def d_step(self, real, z, aug_real, aug_fake, labels=None, cls_z=None, apply=True, gp=None):
+        out = self.d_forward(real, z, aug_real, aug_fake, labels, cls_z, gp)
         params = self.d_params()
         grads = torch.autograd.grad(out["d_loss"], list(params.values()), allow_unused=True)
         gd = OrderedDict((k, (g if g is not None else torch.zeros_like(p)))
@@ -418,6 +445,10 @@ def synthetic_batch(cfg, seed, B=None):
         "aug_fake_d": R.draw_diffaugment(rng, B, S),
         "aug_fake_g": R.draw_diffaugment(rng, B, S),
     }
+    if "wgan" in cfg.gan_type or "dragan" in cfg.gan_type:      # BigGAN.py:719, 726, 729
+        out["gp"] = {"alpha": rng.random(B).astype(np.float32), "aug": R.draw_diffaugment(rng, B, S)}
+        if "dragan" in cfg.gan_type:
+            out["gp"]["eps"] = rng.random((B, S, S, cfg.c_dim)).astype(np.float32)
     if cfg.n_labels:
         def onehot():
             lab = rng.integers(0, cfg.n_labels, B)

@@ -614,15 +614,17 @@ def _sce(labels_one, logits):
 
 
 def discriminator_loss(loss_func, real, fake, flood_level=0):
-    """ops.py:753-797 (the loss types without a gradient penalty)."""
-    if loss_func == "lsgan":
+    """ops.py:753-797 (the penalty of the wgan / dragan types is added by the caller, BigGAN.py:880)."""
+    if "wgan" in loss_func:
+        real_loss, fake_loss = -real.mean(), fake.mean()                    # ops.py:757-759
+    elif loss_func == "lsgan":
         real_loss, fake_loss = ((real - 1.0) ** 2).mean(), (fake ** 2).mean()
     elif loss_func == "ra-lsgan":
         d_xr, d_xf = real - fake.mean(), fake - real.mean()
         real_loss, fake_loss = ((d_xr - 1.0) ** 2).mean(), ((d_xf + 1.0) ** 2).mean()
-    elif loss_func == "gan":
+    elif loss_func in ("gan", "dragan"):
         real_loss, fake_loss = _sce(True, real).mean(), _sce(False, fake).mean()
-    elif loss_func == "ra-gan":
+    elif loss_func in ("ra-gan", "ra-dragan"):
         d_xr, d_xf = real - fake.mean(), fake - real.mean()
         real_loss, fake_loss = _sce(True, d_xr).mean(), _sce(False, d_xf).mean()
     elif loss_func == "ra-hinge":
@@ -641,14 +643,16 @@ def discriminator_loss(loss_func, real, fake, flood_level=0):
 def generator_loss(loss_func, fake, real=None, flood_level=0):
     """ops.py:799-840."""
     real_loss = 0.0
-    if loss_func == "lsgan":
+    if "wgan" in loss_func:
+        fake_loss = -fake.mean()                                            # ops.py:804-805
+    elif loss_func == "lsgan":
         fake_loss = ((fake - 1.0) ** 2).mean()
     elif loss_func == "ra-lsgan":
         d_xr, d_xf = real - fake.mean(), fake - real.mean()
         real_loss, fake_loss = ((d_xr + 1.0) ** 2).mean(), ((d_xf - 1.0) ** 2).mean()
-    elif loss_func == "gan":
+    elif loss_func in ("gan", "dragan"):
         fake_loss = _sce(True, fake).mean()
-    elif loss_func == "ra-gan":
+    elif loss_func in ("ra-gan", "ra-dragan"):
         d_xr, d_xf = real - fake.mean(), fake - real.mean()
         fake_loss, real_loss = _sce(True, d_xf).mean(), _sce(False, d_xr).mean()
     elif loss_func == "ra-hinge":

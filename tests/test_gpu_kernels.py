@@ -509,6 +509,117 @@ def test_bn_renorm_fwd_bwd(N, H, C, per_sample, scale_is_var, weight):
     assert all(torch.equal(a, b) for a, b in zip(before, (mm, mv, rm, rs)))
 
 
+# ---------------------------------------------------------------- second-order pieces of the gradient penalty
+def test_prelu_tangent_fn():
+    """ydot = xdot * prelu'(x): value and gradients w.r.t. xdot and alpha (BigGAN.py:731: tf.gradients through PReLU)."""
+    Fn = _fn()
+    rng = np.random.default_rng(3)
+    x, xd, g = (rng.standard_normal((3, 5, 5, 8)) for _ in range(3))
+    alpha = rng.uniform(0.05, 0.4, 8)
+    xt, xdt, at = torch.tensor(x), torch.tensor(xd, requires_grad=True), torch.tensor(alpha, requires_grad=True)
+    slope = torch.where(xt > 0, torch.ones_like(xt), at.expand_as(xt))
+    yr = xdt * slope
+    (yr * torch.tensor(g)).sum().backward()
+    xdc, ac = cu(xd, True), cu(alpha, True)
+    y = Fn.PReluTangentFn.apply(xdc, cu(x), ac)
+    y.backward(cu(g))
+    assert rel_err(t2n(y), yr.detach().numpy()) < TOL
+    assert rel_err(t2n(xdc.grad), xdt.grad.numpy()) < TOL
+    assert rel_err(t2n(ac.grad), at.grad.numpy()) < 5e-5
+
+
+def test_maxpool_tangent_fn():
+    Fn = _fn()
+    rng = np.random.default_rng(4)
+    x, xd = rng.standard_normal((2, 6, 8, 5)), rng.standard_normal((2, 6, 8, 5))
+    g = rng.standard_normal((2, 3, 4, 5))
+    xt = torch.tensor(x).permute(0, 3, 1, 2)
+    _, idx = F.max_pool2d(xt, 2, 2, return_indices=True)
+    xdt = torch.tensor(xd, requires_grad=True)
+    yr = xdt.permute(0, 3, 1, 2).reshape(2, 5, -1).gather(2, idx.reshape(2, 5, -1)).reshape(2, 5, 3, 4).permute(0, 2, 3, 1)
+    (yr * torch.tensor(g)).sum().backward()
+    xdc = cu(xd, True)
+    y = Fn.MaxPool2TangentFn.apply(xdc, cu(x))
+    y.backward(cu(g))
+    assert rel_err(t2n(y), yr.detach().numpy()) < TOL
+    assert rel_err(t2n(xdc.grad), xdt.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("trans_b", [True, False])
+def test_bmm_fn(trans_b):
+    Fn = _fn()
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((3, 40, 12))
+    b = rng.standard_normal((3, 24, 12) if trans_b else (3, 12, 24))
+    g = rng.standard_normal((3, 40, 24))
+    at, bt = torch.tensor(a, requires_grad=True), torch.tensor(b, requires_grad=True)
+    yr = at @ (bt.transpose(1, 2) if trans_b else bt)
+    (yr * torch.tensor(g)).sum().backward()
+    ac, bc = cu(a, True), cu(b, True)
+    y = Fn.BmmFn.apply(ac, bc, trans_b)
+    y.backward(cu(g))
+    assert rel_err(t2n(y), yr.detach().numpy()) < TOL
+    assert rel_err(t2n(ac.grad), at.grad.numpy()) < TOL
+    assert rel_err(t2n(bc.grad), bt.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("cols", [48, 256, 1024])
+def test_softmax_and_softmax_tangent_fn(cols):
+    """p = softmax(s); pdot = p * (sdot - <p, sdot>): gradients w.r.t. s (through p) and sdot."""
+    Fn = _fn()
+    rng = np.random.default_rng(cols)
+    s_, sd, g, g2 = (rng.standard_normal((2, 7, cols)) for _ in range(4))
+    st, sdt = torch.tensor(s_, requires_grad=True), torch.tensor(sd, requires_grad=True)
+    pr = torch.softmax(st, dim=-1)
+    pdr = pr * (sdt - (pr * sdt).sum(-1, keepdim=True))
+    ((pdr * torch.tensor(g)).sum() + (pr * torch.tensor(g2)).sum()).backward()
+    sc, sdc = cu(s_, True), cu(sd, True)
+    p = Fn.SoftmaxFn.apply(sc)
+    p1, p2 = Fn.ForkFn.apply(p, 2)
+    pd = Fn.SoftmaxTangentFn.apply(p1, sdc)
+    torch.autograd.backward([pd, p2], [cu(g), cu(g2)])
+    assert rel_err(t2n(p), pr.detach().numpy()) < TOL
+    assert rel_err(t2n(pd), pdr.detach().numpy()) < 5e-5
+    assert rel_err(t2n(sdc.grad), sdt.grad.numpy()) < 5e-5
+    assert rel_err(t2n(sc.grad), st.grad.numpy()) < 5e-5
+
+
+@pytest.mark.parametrize("lp,dragan", [(0, False), (1, False), (0, True)])
+def test_gp_interpolate_and_penalty(lp, dragan):
+    """bg_gp_interpolate / bg_gp_penalty (BigGAN.py:718-740) against numpy float64."""
+    from biggan_tensorflow_amd import hip
+    L = hip.lib()
+    rng = np.random.default_rng(7 + lp)
+    B, per = 5, 3 * 16 * 16
+    real, other = rng.uniform(-1, 1, (B, per)), rng.uniform(0, 1, (B, per))
+    alpha = rng.uniform(0, 1, B)
+    rc, oc, alc = cu(real), cu(other), cu(alpha)
+    out = torch.empty_like(rc)
+    if dragan:
+        sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+        hip.check(L.bg_bn_stats(hip.f32(rc), hip.ptr(sums), B * per, 1, hip.stream()))
+        hip.check(L.bg_gp_interpolate(hip.f32(rc), hip.f32(oc), hip.f32(alc), hip.ptr(sums), float(B * per), hip.f32(out),
+                                      B, per, hip.stream()))
+        ref = real + alpha[:, None] * (0.5 * real.std() * other)
+    else:
+        hip.check(L.bg_gp_interpolate(hip.f32(rc), hip.f32(oc), hip.f32(alc), None, 0.0, hip.f32(out), B, per,
+                                      hip.stream()))
+        ref = real + alpha[:, None] * (other - real)
+    assert rel_err(t2n(out), ref) < TOL
+    g = rng.standard_normal((B, per)) * np.array([0.001, 0.02, 0.03, 0.05, 0.0201])[:, None]    # norms around 1
+    gc = cu(g)
+    ws = torch.empty(2 * B, dtype=torch.float64, device="cuda")
+    loss = torch.empty(1, dtype=torch.float32, device="cuda")
+    v = torch.empty_like(gc)
+    hip.check(L.bg_gp_penalty(hip.f32(gc), B, per, float(2 * B), 10.0, lp, hip.ptr(ws), hip.f32(loss), hip.f32(v),
+                              hip.stream()))
+    n = np.sqrt((g ** 2).sum(1))
+    e = np.maximum(n - 1, 0) if lp else n - 1
+    assert (n > 1).any() and (n < 1).any()
+    assert abs(loss.item() - 10.0 * (e ** 2).sum() / (2 * B)) < 1e-5 * max(1.0, loss.item())
+    assert rel_err(t2n(v), (10.0 * 2 * e / n / (2 * B))[:, None] * g) < 5e-5
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 8, 3), (4, 4, 4, 64), (7, 33)])
 def test_prelu(shape):
     Fn = _fn()

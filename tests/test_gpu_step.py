@@ -148,16 +148,24 @@ def _run_parity_once(tr, gan, batch, check_state=True):
     if cfg.gan_type.startswith("ra-"):                 # relativistic losses: the G op reads D(aug(real)) too
         okw_g = dict(real=batch["real"], aug_real=batch["aug_real"])
         hkw_g = dict(real=real, draws_real=a_r)
+    if "gp" in batch:                                  # gradient-penalty types: eps / alpha / DiffAugment draws
+        okw_d = dict(gp=batch["gp"])
+        gpd = {"alpha": cu(batch["gp"]["alpha"]), "aug": dev_draws(batch["gp"]["aug"])}
+        if "eps" in batch["gp"]:
+            gpd["eps"] = cu(batch["gp"]["eps"])
+        hkw_d = dict(gp_draws=gpd)
     if cfg.n_labels:                                   # class-conditional variant
-        okw_d = dict(labels=batch["labels"], cls_z=batch["cls_z_d"])
+        okw_d = dict(okw_d, labels=batch["labels"], cls_z=batch["cls_z_d"])
         okw_g = dict(okw_g, cls_z=batch["cls_z_g"])
-        hkw_d = dict(labels=cu(batch["labels"]), cls_z=cu(batch["cls_z_d"]))
+        hkw_d = dict(hkw_d, labels=cu(batch["labels"]), cls_z=cu(batch["cls_z_d"]))
         hkw_g = dict(hkw_g, cls_z=cu(batch["cls_z_g"]))
 
     # ---------------- gradient parity, D op ----------------
     ro = tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], apply=False, **okw_d)
     ho = gan.d_step(real, z_d, a_r, a_fd, apply=False, **hkw_d)
     assert _loss_close(ho["d_loss"].item(), ro["d_loss"].item()), (ho["d_loss"].item(), ro["d_loss"].item())
+    if "gp" in batch:
+        assert _loss_close(ho["gp"].item(), ro["gp"].item()), (ho["gp"].item(), ro["gp"].item())
     if cfg.n_labels:
         assert _loss_close(ho["d_cls_loss"].item(), ro["d_cls_loss"].item())
     assert rel_err(t2n(ho["real_logits"]), ro["real_logits"].detach().numpy()) < GRAD_TOL
@@ -406,6 +414,17 @@ def test_step_parity_other_gan_losses(gan_type):
     tr = oracle_trainer(64, 8, 64, 4, gan_type=gan_type)
     gan = hip_model_like(tr, gan_type=gan_type)
     batch = RM.synthetic_batch(tr.cfg, 17, 4)
+    _run_parity(tr, gan, batch)
+
+
+@pytest.mark.parametrize("gan_type", ["wgan-gp", "wgan-lp", "dragan", "ra-dragan"])
+def test_step_parity_gradient_penalty(gan_type):
+    """--gan_type wgan-gp / wgan-lp / dragan / ra-dragan (the reference's default; BigGAN.py:717-742, 867-880; SURVEY 8f
+    rank 4): the penalty's value and the whole D-op gradient, whose penalty part needs the second derivative of the
+    discriminator (taken as reverse-over-forward: functional.*TangentFn, ops.Dual), then a full iteration."""
+    tr = oracle_trainer(64, 8, 64, 4, gan_type=gan_type)
+    gan = hip_model_like(tr, gan_type=gan_type)
+    batch = RM.synthetic_batch(tr.cfg, 19, 4)
     _run_parity(tr, gan, batch)
 
 

@@ -155,7 +155,7 @@ def test_sample_grid_png(tmp_path):
 
 
 def test_out_of_scope_flags_rejected_at_build():
-    for extra in (["--g_final_layer", "true"], ["--cls_embedding", "true"], ["--gan_type", "ra-dragan"], ["--g_final_layer", "true"],
+    for extra in (["--g_final_layer", "true"], ["--cls_embedding", "true"], ["--gan_type", "ra-dragan", "--bn_in_d", "true"],
                   ["--z_reconstruct", "true"]):
         argv = ["--gan_type", "hinge", "--img_size", "64"] + extra
         with pytest.raises(NotImplementedError):

@@ -442,3 +442,36 @@ def test_batch_renorm_reductions_and_hand_case():
     yq = (xq - mq) * torch.rsqrt(vq + 1e-5) * (r0 * gam) + bet + d0 * gam
     g_frozen, = torch.autograd.grad((yq * yq).sum(), xq)
     assert torch.allclose(g_auto, g_frozen, atol=1e-10)
+
+
+@pytest.mark.parametrize("gan_type", ["wgan-gp", "wgan-lp", "ra-dragan"])
+def test_gradient_penalty_finite_differences(gan_type):
+    """BigGAN.py:717-742: float64 central differences of d_loss INCLUDING the gradient penalty (whose parameter
+    gradient needs the second derivative of D) on a few discriminator parameters."""
+    cfg = _small_cfg(ch=8, z_dim=64, gan_type=gan_type)
+    tr = M.Trainer(cfg, F64).build()
+    M.perturb_for_parity(tr.vs)
+    batch = M.synthetic_batch(cfg, 11)
+    args = (batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"])
+    out = tr.d_step(*args, apply=False, gp=batch["gp"])
+    assert float(out["gp"].detach()) > 0
+    gd = out["grads"]
+    tr.vs.freeze_uv = True
+    rng = np.random.default_rng(0)
+    eps = 1e-6
+    for name in ("discriminator/resblock_down_2/res1/conv_0/kernel", "discriminator/self_attention/f_conv/kernel",
+                 "discriminator/self_attention/gamma", "discriminator/resblock_down_1/res1/prelu/alpha",
+                 "discriminator/D_logit/kernel"):
+        flat = tr.vs.vars[name].detach().view(-1)
+        for idx in rng.integers(0, flat.numel(), 2):
+            old = flat[idx].item()
+            vals = []
+            for sgn in (1, -1):
+                with torch.no_grad():
+                    flat[idx] = old + sgn * eps
+                vals.append(tr.d_forward(*args, gp=batch["gp"])["d_loss"].item())
+            with torch.no_grad():
+                flat[idx] = old
+            fd = (vals[0] - vals[1]) / (2 * eps)
+            an = gd[name].reshape(-1)[idx].item()
+            assert abs(fd - an) <= 2e-5 * max(1e-3, abs(an), abs(fd)) + 1e-8, (name, idx, fd, an)
