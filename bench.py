@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--da_policy", type=str, default="full")
     ap.add_argument("--g_regularization", type=str, default="ortho_cosine")
     ap.add_argument("--n_labels", type=int, default=0, help="class-conditional variant: synthetic one-hot labels")
+    ap.add_argument("--gan_type", type=str, default="hinge",
+                    help="BASELINE's configs use hinge; e.g. ra-dragan (the reference's default) adds the gradient penalty")
     ap.add_argument("--graph", action="store_true", help="replay the iteration from captured HIP graphs (N=1 only)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
@@ -182,7 +184,7 @@ def main():
     img, ch, B, desc = WORKLOADS[a.workload]
     if a.batch:
         B = a.batch
-    argv = ["--gan_type", "hinge", "--img_size", str(img), "--ch", str(ch), "--batch_size", str(B),
+    argv = ["--gan_type", a.gan_type, "--img_size", str(img), "--ch", str(ch), "--batch_size", str(B),
             "--da_policy", a.da_policy, "--g_regularization", a.g_regularization, "--n_labels", str(a.n_labels)]
     args = M.parse_args(argv, make_dirs=False)
     bf16 = a.workload in BF16_WORKLOADS
@@ -265,7 +267,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": desc, "img_size": img, "ch": ch, "per_gpu_batch": B, "global_batch": B * world,
-                       "da_policy": a.da_policy, "g_regularization": a.g_regularization, "n_labels": a.n_labels, "hip_graph": bool(a.graph),
+                       "da_policy": a.da_policy, "g_regularization": a.g_regularization, "n_labels": a.n_labels, "gan_type": a.gan_type, "hip_graph": bool(a.graph),
                        "parallelism": "dp%d" % world},
             "losses": {k: round(float(v.item()), 5) for k, v in losses.items()},
         }

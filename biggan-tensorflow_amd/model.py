@@ -542,8 +542,11 @@ class BigGAN(GANBase):
         if self.gradient_penalty_type == 'dragan':
             sums = torch.zeros(2, dtype=torch.float64, device=self.device)
             Fn.check(L.bg_bn_stats(Fn.f32(real), Fn.hip.ptr(sums), real.numel(), 1, Fn.stream()))
+            if self._reduce_fn() is not None:          # the moments of the GLOBAL real batch (BigGAN.py:720)
+                self._reduce_fn()(sums)
             Fn.check(L.bg_gp_interpolate(Fn.f32(real), Fn.f32(draws["eps"].contiguous()), Fn.f32(draws["alpha"]),
-                                         Fn.hip.ptr(sums), float(real.numel()), Fn.f32(xhat), B, per, Fn.stream()))
+                                         Fn.hip.ptr(sums), float(real.numel() * self.world), Fn.f32(xhat), B, per,
+                                         Fn.stream()))
         else:
             Fn.check(L.bg_gp_interpolate(Fn.f32(real), Fn.f32(fake.detach().contiguous()), Fn.f32(draws["alpha"]), None,
                                          0.0, Fn.f32(xhat), B, per, Fn.stream()))
@@ -763,6 +766,8 @@ class BigGAN(GANBase):
         run_g = (self.counter - 1) % self.n_critic == 0                               # BigGAN.py:1080
         d = self.d_step(real, labels=labels, defer=run_g)
         losses["d_loss"] = d["d_loss"]
+        if d.get("gp") is not None:
+            losses["gp"] = d["gp"]
         if run_g:
             # (the reference's g_ops pull a fresh real batch from the input iterator; the D step's batch is reused here)
             g = self.g_step(first.shape[0], after_generator=self._finish_d, real=real if self.relativistic else None)

@@ -28,7 +28,20 @@ def _slice_draws(d, lo, hi):
     return {k: v[lo:hi] for k, v in d.items()}
 
 
-def _worker(rank, world, port, q):
+def _extra(batch, tr, cu, dev_draws, lo, hi):
+    """Keyword arguments of the D op (gradient-penalty draws) and the G op (real batch of the relativistic types)."""
+    dkw, gkw = {}, {}
+    if "gp" in batch:
+        gp = {"alpha": cu(batch["gp"]["alpha"][lo:hi]), "aug": dev_draws(_slice_draws(batch["gp"]["aug"], lo, hi))}
+        if "eps" in batch["gp"]:
+            gp["eps"] = cu(batch["gp"]["eps"][lo:hi])
+        dkw["gp_draws"] = gp
+    if tr.cfg.gan_type.startswith("ra-"):
+        gkw = dict(real=cu(batch["real"][lo:hi]), draws_real=dev_draws(_slice_draws(batch["aug_real"], lo, hi)))
+    return dkw, gkw
+
+
+def _worker(rank, world, port, q, gan_type="hinge"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
@@ -41,8 +54,8 @@ def _worker(rank, world, port, q):
     from tests.common import oracle_trainer, hip_model_like, dev_draws, t2n
     torch.cuda.set_device(0)
     parallel.init_from_env(backend="gloo")
-    tr = oracle_trainer(IMG, CH, ZD, B)              # same seed on both ranks: identical replicas
-    gan = hip_model_like(tr)
+    tr = oracle_trainer(IMG, CH, ZD, B, gan_type=gan_type)     # same seed on both ranks: identical replicas
+    gan = hip_model_like(tr, gan_type=gan_type)
     assert gan.world == world and gan.rank == rank
     batch = RM.synthetic_batch(tr.cfg, 5, B)
     lo, hi = parallel.shard_batch(B, rank, world)
@@ -50,23 +63,25 @@ def _worker(rank, world, port, q):
     def cu(a):
         return torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda")
     out = {}
+    dkw, gkw = _extra(batch, tr, cu, dev_draws, lo, hi)
     d = gan.d_step(cu(batch["real"][lo:hi]), cu(batch["z_d"][lo:hi]), dev_draws(_slice_draws(batch["aug_real"], lo, hi)),
-                   dev_draws(_slice_draws(batch["aug_fake_d"], lo, hi)), apply=False)
+                   dev_draws(_slice_draws(batch["aug_fake_d"], lo, hi)), apply=False, **dkw)
     out["d_loss"] = d["d_loss"].item()
     out["d_grads"] = t2n(gan.d_arena.grads).copy()
     hip0 = {k: v for k, v in tr.vs.export().items()}
     gan.store.load_arrays({k: v.astype(np.float32) for k, v in hip0.items()}, reset_ema=False)
-    g = gan.g_step(hi - lo, cu(batch["z_g"][lo:hi]), dev_draws(_slice_draws(batch["aug_fake_g"], lo, hi)), apply=False)
+    g = gan.g_step(hi - lo, cu(batch["z_g"][lo:hi]), dev_draws(_slice_draws(batch["aug_fake_g"], lo, hi)), apply=False,
+                   **gkw)
     out["g_adv"] = g["g_adv"].item()
     out["g_grads"] = t2n(gan.g_arena.grads).copy()
     # one full iteration the way train_step runs it under data parallelism: the D all-reduce is started
     # asynchronously and finished (wait + Adam) after the G step's generator forward
     gan.store.load_arrays({k: v.astype(np.float32) for k, v in hip0.items()}, reset_ema=True)
     gan.d_step(cu(batch["real"][lo:hi]), cu(batch["z_d"][lo:hi]), dev_draws(_slice_draws(batch["aug_real"], lo, hi)),
-               dev_draws(_slice_draws(batch["aug_fake_d"], lo, hi)), defer=True)
+               dev_draws(_slice_draws(batch["aug_fake_d"], lo, hi)), defer=True, **dkw)
     assert gan._pending_d is not None
     gan.g_step(hi - lo, cu(batch["z_g"][lo:hi]), dev_draws(_slice_draws(batch["aug_fake_g"], lo, hi)),
-               after_generator=gan._finish_d)
+               after_generator=gan._finish_d, **gkw)
     assert gan._pending_d is None
     out["d_params"] = t2n(gan.d_arena.params).copy()
     out["g_params"] = t2n(gan.g_arena.params).copy()
@@ -75,27 +90,28 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def _single():
+def _single(gan_type="hinge"):
     from oracle import ref_model as RM
     from tests.common import oracle_trainer, hip_model_like, dev_draws, t2n
-    tr = oracle_trainer(IMG, CH, ZD, B)
-    gan = hip_model_like(tr)
+    tr = oracle_trainer(IMG, CH, ZD, B, gan_type=gan_type)
+    gan = hip_model_like(tr, gan_type=gan_type)
     batch = RM.synthetic_batch(tr.cfg, 5, B)
 
     def cu(a):
         return torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda")
     out = {}
+    dkw, gkw = _extra(batch, tr, cu, dev_draws, 0, B)
     d = gan.d_step(cu(batch["real"]), cu(batch["z_d"]), dev_draws(batch["aug_real"]), dev_draws(batch["aug_fake_d"]),
-                   apply=False)
+                   apply=False, **dkw)
     out["d_loss"] = d["d_loss"].item()
     out["d_grads"] = t2n(gan.d_arena.grads).copy()
     gan.store.load_arrays({k: v.astype(np.float32) for k, v in tr.vs.export().items()}, reset_ema=False)
-    g = gan.g_step(B, cu(batch["z_g"]), dev_draws(batch["aug_fake_g"]), apply=False)
+    g = gan.g_step(B, cu(batch["z_g"]), dev_draws(batch["aug_fake_g"]), apply=False, **gkw)
     out["g_adv"] = g["g_adv"].item()
     out["g_grads"] = t2n(gan.g_arena.grads).copy()
     gan.store.load_arrays({k: v.astype(np.float32) for k, v in tr.vs.export().items()}, reset_ema=True)
-    gan.d_step(cu(batch["real"]), cu(batch["z_d"]), dev_draws(batch["aug_real"]), dev_draws(batch["aug_fake_d"]))
-    gan.g_step(B, cu(batch["z_g"]), dev_draws(batch["aug_fake_g"]))
+    gan.d_step(cu(batch["real"]), cu(batch["z_d"]), dev_draws(batch["aug_real"]), dev_draws(batch["aug_fake_d"]), **dkw)
+    gan.g_step(B, cu(batch["z_g"]), dev_draws(batch["aug_fake_g"]), **gkw)
     out["d_params"] = t2n(gan.d_arena.params).copy()
     out["g_params"] = t2n(gan.g_arena.params).copy()
     return out
@@ -105,13 +121,17 @@ def _rel(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
 
 
-def test_two_rank_data_parallel_matches_single_process():
-    ref = _single()
+@pytest.mark.parametrize("gan_type", ["hinge", "ra-dragan"])
+def test_two_rank_data_parallel_matches_single_process(gan_type):
+    """hinge: the BASELINE path.  ra-dragan (the reference's default --gan_type): relativistic batch means, the
+    global moments of the real batch behind the DRAGAN perturbation and the gradient penalty's global mean all cross
+    the rank boundary."""
+    ref = _single(gan_type)
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, gan_type)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(world))
