@@ -5,7 +5,7 @@ eagerly on one MI355X per process.  One training iteration = D step then G step
 power iteration per weight.
 
 Out-of-scope reference features (alternative heads, reconstruction heads, label
-embeddings, mixed-kernel blocks, gradient-penalty losses) are accepted as flags and rejected here with
+embeddings, mixed-kernel blocks) are accepted as flags and rejected here with
 NotImplementedError.
 """
 import copy

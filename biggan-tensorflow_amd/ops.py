@@ -834,7 +834,7 @@ def spectral_norm(w, iteration=1, _shape_only=False):
 # Loss function
 ##################################################################################
 def discriminator_loss(loss_func, real, fake, flood_level=0):
-    """ops.py:753-797 ('hinge' branch)."""
+    """ops.py:753-797 (the gradient penalty of the wgan / dragan types is added by the caller, BigGAN.py:880)."""
     if loss_func == 'hinge':
         return Fn.HingeDLossFn.apply(real, fake, flood_level, _run.reduce_fn, _run.world)
     if loss_func in Fn.GAN_LOSS_KINDS:
@@ -851,7 +851,7 @@ def generator_loss(loss_func, fake, real, flood_level=0):
             raise ValueError("generator_loss('%s') is relativistic: it needs the real logits" % loss_func)
         r = real if loss_func.startswith('ra-') else None
         return Fn.GanLossFn.apply(r, fake, Fn.GAN_LOSS_KINDS[loss_func], 1, flood_level, _run.reduce_fn, _run.world)
-    raise NotImplementedError("generator_loss('%s'): gradient-penalty losses are not implemented" % loss_func)
+    raise ValueError("generator_loss: unknown loss '%s'" % loss_func)
 
 
 def glu(x, opt=None):
