@@ -140,6 +140,15 @@ struct BnStatsFn {
     }
 };
 
+// inference: normalise with the population statistics (ops.py:643; tf.layers.batch_normalization(training=False))
+__global__ void bn_population_kernel(const float* __restrict__ pop_mean, const float* __restrict__ pop_var, float eps,
+                                     float* __restrict__ mean, float* __restrict__ rstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = pop_mean[c];
+    rstd[c] = rsqrtf(pop_var[c] + eps);
+}
+
 __global__ void bn_finalize_kernel(const double* sums, double count, float eps, float momentum, int unbiased,
                                    float* mean, float* rstd, float* mm, float* mv, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1099,6 +1108,15 @@ int bg_bn_finalize(const double* sums, double count, float eps, float momentum, 
     BG_REQUIRE(sums && mean && rstd && C > 0 && count > 0, "bg_bn_finalize: bad argument");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count, eps,
                        momentum, unbiased_moving_var, mean, rstd, moving_mean, moving_var, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_bn_population(const float* pop_mean, const float* pop_var, float eps, float* mean, float* rstd, int C,
+                     void* stream) {
+    BG_REQUIRE(pop_mean && pop_var && mean && rstd && C > 0, "bg_bn_population: bad argument");
+    hipLaunchKernelGGL(bn_population_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), pop_mean, pop_var,
+                       eps, mean, rstd, C);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -498,10 +498,7 @@ class BnActFn(Function):
                                    f32(moving_mean), f32(moving_var), C, stream()))
         else:
             # inference: population statistics (ops.py:643)
-            sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
-            sums[:C].copy_(moving_mean)
-            sums[C:].copy_(moving_var + moving_mean * moving_mean)
-            check(L.bg_bn_finalize(hip.ptr(sums), 1.0, eps, 0.0, 0, f32(mean), f32(rstd), None, None, C, stream()))
+            check(L.bg_bn_population(f32(moving_mean), f32(moving_var), eps, f32(mean), f32(rstd), C, stream()))
         y = torch.empty_like(x)
         gamma_c, beta_c = _c(gamma), _c(beta)
         ctx.renorm_rd = None

@@ -83,6 +83,7 @@ SIGNATURES = {
     "bg_bn_apply_act_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "bg_bn_apply_act_bwd_dx": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "bg_bn_bwd_finalize": (c_int, [_P, _P, c_int, c_double, _P, _P, _P, _P, c_int, c_int, _P]),
+    "bg_bn_population": (c_int, [_P, _P, c_float, _P, _P, c_int, _P]),
     "bg_renorm_coeffs": (c_int, [_P, c_double, _P, _P, c_int, _P, c_float, c_float, c_float, c_float, c_float, c_float,
                                  c_int, _P, _P, c_int, _P]),
     "bg_renorm_affine_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P]),

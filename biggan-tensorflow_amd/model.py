@@ -733,13 +733,13 @@ class BigGAN(GANBase):
                 # the SUM all-reduce of the flat gradient arena then yields the single-process gradient
                 torch.autograd.backward(roots, [ones] * len(roots))
                 self._sn_backward("generator")
-                if out["regs"]:
-                    out["g_reg"] = torch.stack([r.detach() for r in out["regs"]]).sum().reshape(1)
-                else:
-                    out["g_reg"] = torch.zeros(1, device=self.device)
+                out["g_reg"] = torch.zeros(1, dtype=torch.float32, device=self.device)
+                if out["regs"]:                                     # reported value: column sum of the terms
+                    terms = torch.cat([r.detach().reshape(1) for r in out["regs"]]).reshape(-1, 1)
+                    Fn._bias_grad(terms, out["g_reg"])
                 if self.world > 1 and self.g_regularization_method != 'none':
-                    self._reduce_fn()(out["g_reg"])                 # reported value: sum over the owners
-                out["g_loss"] = out["g_adv"].detach() + out["g_reg"]
+                    self._reduce_fn()(out["g_reg"])                 # sum over the owners
+                out["g_loss"] = Fn.axpby(out["g_reg"], 1.0, out["g_adv"].detach().clone().reshape(1), 1.0)
                 outs.append(out)
         finally:
             self._set_requires_grad(self.d_vars, True)

@@ -193,6 +193,9 @@ int bg_spectral_norm_batch_bwd(const BgSnItem* items_dev, int n_items, const uin
 int bg_bn_stats(const float* x, double* sums, int64_t rows, int C, void* stream);
 int bg_bn_finalize(const double* sums, double count, float eps, float momentum, int unbiased_moving_var,
                    float* mean, float* rstd, float* moving_mean, float* moving_var, int C, void* stream);
+/* inference (ops.py:640-643): mean = pop_mean, rstd = 1/sqrt(pop_var + eps) for the apply kernel below */
+int bg_bn_population(const float* pop_mean, const float* pop_var, float eps, float* mean, float* rstd, int C,
+                     void* stream);
 int bg_bn_apply_act_fwd(const float* x, const float* mean, const float* rstd,
                         const float* gamma, const float* beta, int per_sample,
                         const float* alpha, float* y, int N, int HW, int C, void* stream);

@@ -22,8 +22,8 @@ WEIGHT_SEED, BATCH_SEED = 42, 5
 N_SAMPLE = 8
 
 
-def build():
-    cfg = RM.Config(img_size=CFG["img_size"], ch=CFG["ch"], z_dim=CFG["z_dim"], batch_size=CFG["batch"])
+def build(**cfg_kw):
+    cfg = RM.Config(img_size=CFG["img_size"], ch=CFG["ch"], z_dim=CFG["z_dim"], batch_size=CFG["batch"], **cfg_kw)
     tr = RM.Trainer(cfg, torch.float64, WEIGHT_SEED).build()
     RM.perturb_for_parity(tr.vs)
     for k, p in tr.g_params().items():
@@ -75,8 +75,26 @@ def compute():
     return out
 
 
+def compute_gp(gan_type="ra-dragan"):
+    """step_img64_ch8_radragan.npz: the D op of the reference's DEFAULT --gan_type (relativistic loss + DRAGAN gradient
+    penalty, BigGAN.py:717-742): loss, penalty, logits and every first-step D gradient (norm + sampled elements)."""
+    tr, batch = build(gan_type=gan_type)
+    out = {}
+    d = tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], apply=False, gp=batch["gp"])
+    out["d_loss"] = np.array(d["d_loss"].item())
+    out["gp"] = np.array(d["gp"].item())
+    out["real_logits"] = d["real_logits"].detach().numpy()
+    out["fake_logits_d"] = d["fake_logits"].detach().numpy()
+    for k, g in d["grads"].items():
+        g = g.numpy().reshape(-1)
+        out["dgrad_norm/" + k] = np.array(np.linalg.norm(g))
+        out["dgrad_samp/" + k] = g[stable_indices(k, g.size)]
+    return out
+
+
 if __name__ == "__main__":
-    res = compute()
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "step_img64_ch8.npz")
-    np.savez_compressed(path, **res)
-    print("wrote", path, os.path.getsize(path), "bytes,", len(res), "arrays")
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name, res in (("step_img64_ch8.npz", compute()), ("step_img64_ch8_radragan.npz", compute_gp())):
+        path = os.path.join(here, name)
+        np.savez_compressed(path, **res)
+        print("wrote", path, os.path.getsize(path), "bytes,", len(res), "arrays")
