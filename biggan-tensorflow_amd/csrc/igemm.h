@@ -46,6 +46,8 @@ struct NNParams {
     int32_t tiles_m, tiles_n;
     int32_t kchunk;         // K-steps per channel chunk of the (chunk, tap, step) K order; 0 = all channels
     int32_t zfold;          // >0: gridDim.z folded into blockIdx.x, z fastest (phases of one M-tile share an L2)
+    const void* A16;        // bf16 copy of A (same element offsets) for the bf16-source kernels, or null
+    const void* B16;        // bf16 copy of B
 };
 
 struct TNParams {

@@ -607,10 +607,51 @@ static void launch_slab_reduce(const float* ws, float* out, int64_t n, int split
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, out, n, splitk, slab);
 }
 
+// fp32 -> bf16 copy (RNE) of a whole operand for the bf16-source kernels (n % 8 == 0, 16-byte aligned)
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float4 a = ld4(x + i * 8), b = ld4(x + i * 8 + 4);
+        *reinterpret_cast<bf16x8*>(y + i * 8) = cvt8(a, b);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Device scratch for the bf16 operand copies: grow-only, owned by the library, used in stream order (one stream).
+struct Bf16Scratch {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    void* get(size_t need) {
+        if (need <= bytes) return ptr;
+        if (ptr) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(ptr);
+        }
+        need = (need + (size_t(1) << 24)) & ~((size_t(1) << 24) - 1);
+        if (hipMalloc(&ptr, need) != hipSuccess) {
+            ptr = nullptr;
+            bytes = 0;
+            return nullptr;
+        }
+        bytes = need;
+        return ptr;
+    }
+};
+static Bf16Scratch g_a16, g_b16;
+
+static bool to_bf16(const float* x, int64_t n, Bf16Scratch& sc, const void** out, hipStream_t s) {
+    if (n <= 0 || (n & 7) || !aligned16(x)) return false;
+    void* dst = sc.get((size_t)n * 2);
+    if (!dst) return false;
+    int64_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, reinterpret_cast<__bf16*>(dst), n / 8);
+    *out = dst;
+    return true;
+}
 
 struct NNPlan {
     int bm, bn, splitk;
@@ -698,6 +739,17 @@ static void launch_nn_tile(NNParams& p, const NNPlan& pl, bool vec, bool bf16, i
         p.zfold = zdim;
         grid = dim3(p.tiles_m * p.tiles_n * zdim, 1, 1);
     }
+    if constexpr (MODE != GATHER_PLAIN && !MIRROR) {
+        if (bf16 && vec && pl.bn >= 64 && p.A16 && p.B16) {
+            if (pl.bm == 128 && pl.bn == 128)
+                hipLaunchKernelGGL((nn_kernel_bf16<2, 2, BT, MODE, false, true>), grid, dim3(256), 0, s, p);
+            else if (pl.bm == 128 && pl.bn == 64)
+                hipLaunchKernelGGL((nn_kernel_bf16<2, 1, BT, MODE, false, true>), grid, dim3(256), 0, s, p);
+            else
+                hipLaunchKernelGGL((nn_kernel_bf16<1, 1, BT, MODE, false, true>), grid, dim3(256), 0, s, p);
+            return;
+        }
+    }
     if (bf16 && vec && pl.bn >= 64) {
         if (pl.bm == 128 && pl.bn == 128)
             hipLaunchKernelGGL((nn_kernel_bf16<2, 2, BT, MODE, MIRROR>), grid, dim3(256), 0, s, p);
@@ -734,6 +786,16 @@ static int launch_nn(NNParams& p, int mode, bool bt, bool mirror, bool vec, int 
     p.splitk = pl.splitk;
     p.slabs = reinterpret_cast<float*>(ws);
     p.slab_stride = out_elems;
+    p.A16 = p.B16 = nullptr;
+    // mode 3 (experimental): whole-operand bf16 copies + the bf16-source kernel, i.e. the kernel a bf16-resident
+    // activation layout will use; with fp32 tensors in HBM the two conversion passes cost what the kernel gains
+    if (g_gemm_compute.load() >= 3 && bf16 && vec && pl.bn >= 64 && mode != GATHER_PLAIN && !mirror && p.C % 8 == 0 && p.N % 8 == 0 &&
+        p.g.ld % 8 == 0 && (mode == GATHER_TCONV ? p.ldn % 8 == 0 : p.ldk % 8 == 0)) {
+        const int64_t a_elems = (int64_t)p.g.Nb * p.g.Hs * p.g.Ws * p.g.ld;
+        const int64_t b_elems = (int64_t)p.g.k * p.g.k * p.tap_stride;
+        if (!to_bf16(p.A, a_elems, g_a16, &p.A16, s) || !to_bf16(p.B, b_elems, g_b16, &p.B16, s))
+            p.A16 = p.B16 = nullptr;
+    }
     if (mode == GATHER_CONV)
         launch_nn_tile<false, GATHER_CONV, false>(p, pl, vec, bf16, zdim, s);
     else if (mode == GATHER_TCONV && mirror)
@@ -973,7 +1035,7 @@ using namespace bg;
 
 extern "C" {
 
-void bg_set_gemm_compute(int mode) { g_gemm_compute.store(mode == 1 || mode == 2 ? mode : 0); }
+void bg_set_gemm_compute(int mode) { g_gemm_compute.store(mode >= 1 && mode <= 3 ? mode : 0); }
 int bg_get_gemm_compute(void) { return g_gemm_compute.load(); }
 
 size_t bg_conv2d_fwd_workspace_bytes(const BgConvDesc* d) {
@@ -1125,7 +1187,7 @@ size_t bg_gemm_workspace_bytes(const BgGemmDesc* d) {
 // compute mode 2: the large plain GEMMs too (regulariser Grams and their gradients: batch-independent
 // work that is 20 % of the step at ch = 96, batch 32); small / skinny ones (dense layers, cond-BN FCs) stay fp32
 static bool gemm_wants_bf16(const BgGemmDesc* d) {
-    return g_gemm_compute.load() == 2 && d->M >= 128 && d->N >= 128 && d->K >= 128;
+    return g_gemm_compute.load() >= 2 && d->M >= 128 && d->N >= 128 && d->K >= 128;
 }
 
 int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bias, const float* alpha_dev,

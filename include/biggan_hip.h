@@ -56,7 +56,12 @@ typedef struct BgConvDesc {
  *   0 = fp32 MFMA (default; the reference's precision, ops.py:14)
  *   1 = bf16 MFMA with fp32 accumulation: operands are rounded to bf16 (RNE) while they are staged
  *       into LDS; tensors in HBM, outputs, dense layers, attention and every other kernel stay fp32.
- *   2 = 1 + bg_gemm launches with M, N, K >= 128 (the regulariser's Gram matrices and their gradients). */
+ *   2 = 1 + bg_gemm launches with M, N, K >= 128 (the regulariser's Gram matrices and their gradients).
+ *   3 = 2 + (experimental) conv / transposed-conv forward and input-gradient launches read BOTH operands from
+ *       whole-tensor bf16 copies made per call into library-owned device scratch (grow-only, used in stream order
+ *       on one stream): the kernel variant a bf16-resident activation layout will use.  Same results as mode 1
+ *       (RNE rounding happens in the copy instead of in the staging loop).  Measured in round 1: the kernel alone
+ *       gains 5-23 % on the deep layers, the copies cost as much; not used by bench.py. */
 void bg_set_gemm_compute(int mode);
 int  bg_get_gemm_compute(void);
 

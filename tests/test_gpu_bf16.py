@@ -20,16 +20,39 @@ def cu(a, grad=False):
     return t
 
 
-@pytest.fixture
-def bf16_mode():
+@pytest.fixture(params=[1, 3])
+def bf16_mode(request):
+    """1: operands rounded while they are staged into LDS; 3: whole-operand bf16 copies + the bf16-source kernel."""
     import biggan_tensorflow_amd  # noqa: F401
     from biggan_tensorflow_amd import hip
     L = hip.lib()
-    L.bg_set_gemm_compute(1)
-    assert L.bg_get_gemm_compute() == 1
+    L.bg_set_gemm_compute(request.param)
+    assert L.bg_get_gemm_compute() == request.param
     yield
     L.bg_set_gemm_compute(0)
     assert L.bg_get_gemm_compute() == 0
+
+
+def test_bf16_source_kernels_equal_staged_rounding():
+    """Mode 3 rounds the same values the same way (RNE) and accumulates in the same order as mode 1: bit-identical."""
+    import biggan_tensorflow_amd  # noqa: F401
+    from biggan_tensorflow_amd import hip, functional as Fn
+    L = hip.lib()
+    rng = np.random.default_rng(0)
+    x = cu(rng.standard_normal((4, 16, 16, 128)))
+    wc = cu(rng.standard_normal((3, 3, 128, 256)) * 0.05)
+    wd = cu(rng.standard_normal((4, 4, 64, 128)) * 0.05)
+    outs = {}
+    try:
+        for mode in (1, 3):
+            L.bg_set_gemm_compute(mode)
+            outs[mode] = (Fn.Conv2dFn.apply(x, wc, None, 1, 1, 16, 16, hip.PAD_REFLECT).clone(),
+                          Fn.Conv2dFn.apply(x, wc, None, 2, 1, 8, 8, hip.PAD_ZERO).clone(),
+                          Fn.Deconv2dFn.apply(x, wd, None, 2, 1, None).clone())
+    finally:
+        L.bg_set_gemm_compute(0)
+    for a, b in zip(outs[1], outs[3]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("N,H,Cin,Cout,k,s", [(2, 16, 64, 128, 3, 1), (2, 16, 64, 64, 3, 2), (4, 8, 128, 256, 3, 1),
