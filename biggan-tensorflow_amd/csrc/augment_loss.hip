@@ -555,6 +555,25 @@ __global__ __launch_bounds__(AL_BLOCK) void gp_scale_kernel(const float* __restr
         v[i] = (float)coeff[i / per] * g[i];
 }
 
+// S = A + A^T for a c x c matrix (32 x 32 tiles through LDS): the regulariser's backward W dA + W dA^T becomes
+// one GEMM W S instead of two
+__global__ __launch_bounds__(AL_BLOCK) void symmetrize_kernel(const float* __restrict__ A, float* __restrict__ S, int c) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int row = bx + r, col = by + tx;                       // transposed block
+        tile[r][tx] = (row < c && col < c) ? A[(int64_t)row * c + col] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int row = by + r, col = bx + tx;
+        if (row < c && col < c) S[(int64_t)row * c + col] = A[(int64_t)row * c + col] + tile[tx][r];
+    }
+}
+
 // plain 'ortho' regulariser (utils.py:199-200): reg = A - I, loss = scale * l2_loss(reg), dA = scale * reg
 __global__ __launch_bounds__(AL_BLOCK) void ortho_identity_kernel(const float* __restrict__ A, float scale,
                                                                    float* loss_accum, float* __restrict__ dA, int c) {
@@ -765,6 +784,14 @@ int bg_gp_penalty(const float* g, int N, int64_t per, double count_global, float
     int64_t blocks = (total + AL_BLOCK - 1) / AL_BLOCK;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(gp_scale_kernel, dim3((unsigned)blocks), dim3(AL_BLOCK), 0, st, g, ws + N, v, per, total);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_symmetrize(const float* A, float* S, int c, void* stream) {
+    BG_REQUIRE(A && S && A != S && c > 0, "bg_symmetrize: bad argument");
+    const unsigned nb = (unsigned)((c + 31) / 32);
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(nb, nb), dim3(AL_BLOCK), 0, as_stream(stream), A, S, c);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -1162,8 +1162,9 @@ class OrthoCosineRegFn(Function):
 
         def prod(out):
             o2 = out.view(rows, c)
-            gemm(W2, dA, o2, rows, c, c, c, c, c, alpha_dev=g)                                  # W dA
-            gemm(W2, dA, o2, rows, c, c, c, c, c, transB=True, alpha_dev=g, accumulate=True)    # + W dA^T
+            S_ = torch.empty_like(dA)
+            check(lib().bg_symmetrize(f32(dA), f32(S_), c, stream()))
+            gemm(W2, S_, o2, rows, c, c, c, c, c, alpha_dev=g)                                  # W dA + W dA^T = W (dA + dA^T)
         dw = param_grad(w, ctx.needs_input_grad[0], prod)
         ctx.w = ctx.dA = None
         return dw, None, None

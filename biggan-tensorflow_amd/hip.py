@@ -88,6 +88,7 @@ SIGNATURES = {
                                  c_int, _P, _P, c_int, _P]),
     "bg_renorm_affine_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "bg_renorm_affine_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P]),
+    "bg_symmetrize": (c_int, [_P, _P, c_int, _P]),
     "bg_gp_interpolate": (c_int, [_P, _P, _P, _P, c_double, _P, c_int, c_int64, _P]),
     "bg_gp_penalty": (c_int, [_P, c_int, c_int64, c_double, c_float, c_int, _P, _P, _P, _P]),
     "bg_maxpool2_gather": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

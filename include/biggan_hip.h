@@ -365,6 +365,8 @@ int bg_sigmoid_ce(const float* logits, const float* truth, const float* weights,
  * ------------------------------------------------------------------------------------------ */
 int bg_ortho_cosine_fwd_bwd(const float* A, float scale, float* loss_accum, float* dA, int c, void* stream);
 /* type 'ortho' (utils.py:199-200): loss_accum += scale/2 * sum (A - I)^2, dA = scale * (A - I). */
+/* S = A + A^T (c x c, out of place): d(loss)/dW = W dA + W dA^T = W S, one GEMM instead of two (utils.py:197-203) */
+int bg_symmetrize(const float* A, float* S, int c, void* stream);
 int bg_ortho_identity_fwd_bwd(const float* A, float scale, float* loss_accum, float* dA, int c, void* stream);
 /* Low-rank form of the same function for wide kernels W[rows, c] with rows < c (first/dense2 is
  * [184, 16*16*ch]): with G = W W^T, s = W 1, P = G W (bg_gemm) the c x c Gram matrix is never formed.

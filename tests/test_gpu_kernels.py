@@ -620,6 +620,17 @@ def test_gp_interpolate_and_penalty(lp, dragan):
     assert rel_err(t2n(v), (10.0 * 2 * e / n / (2 * B))[:, None] * g) < 5e-5
 
 
+@pytest.mark.parametrize("c", [8, 33, 96, 200])
+def test_symmetrize(c):
+    from biggan_tensorflow_amd import hip
+    rng = np.random.default_rng(c)
+    a = rng.standard_normal((c, c))
+    ac = cu(a)
+    out = torch.empty_like(ac)
+    hip.check(hip.lib().bg_symmetrize(hip.f32(ac), hip.f32(out), c, hip.stream()))
+    assert np.array_equal(t2n(out), (ac + ac.t()).cpu().numpy())
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 8, 3), (4, 4, 4, 64), (7, 33)])
 def test_prelu(shape):
     Fn = _fn()
