@@ -895,6 +895,15 @@ static int launch_tn(TNParams& p, int mode, bool vec, float* final_out, void* ws
         p.zfold = p.splitk;
         grid = dim3(p.tiles_m * p.tiles_n * p.splitk, 1, 1);
     }
+    static const int tn_tr = getenv("BG_TN_TR") ? atoi(getenv("BG_TN_TR")) : 1;   // hardware-transposed operand reads (0: VALU transposition)
+    if (tn_tr && bf16 && pl.bm == 128 && pl.bn == 128 && p.Ca % 8 == 0 && p.Cb % 8 == 0) {
+        if (mode == GATHER_CONV)
+            hipLaunchKernelGGL((tn_kernel_bf16_tr<GATHER_CONV>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((tn_kernel_bf16_tr<GATHER_PLAIN>), grid, dim3(256), 0, s, p);
+        BG_LAUNCH_CHECK();
+        goto tn_reduce;
+    }
     if (bf16 && pl.bn >= 64 && mode == GATHER_CONV) {
         if (pl.bm == 128 && pl.bn == 128)
             hipLaunchKernelGGL((tn_kernel_bf16<2, 2, GATHER_CONV>), grid, dim3(256), 0, s, p);
@@ -918,6 +927,7 @@ static int launch_tn(TNParams& p, int mode, bool vec, float* final_out, void* ws
     else
         launch_tn_inst<1, 1, 4, 1>(p, mode, vec, grid, s);     // 128 x 32
     BG_LAUNCH_CHECK();
+tn_reduce:
     if (pl.splitk > 1) {
         launch_slab_reduce(reinterpret_cast<const float*>(ws), final_out, total, pl.splitk, total, s);
         BG_LAUNCH_CHECK();

@@ -552,4 +552,207 @@ __global__ __launch_bounds__(256) void tn_kernel_bf16(const TNParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// TN kernel, bf16 compute, hardware-transposed operand reads (gfx950 ds_read_b64_tr_b16).
+//   The tiles stay PIXEL-major in LDS ([32 pixels][128 channels] bf16, 256-byte rows, 16-byte chunks XOR-swizzled
+//   by (row & 3) << 2 | (row >> 2) & 3): the staging pass is a conversion plus one conflict-free 16-byte write per
+//   (pixel, 8 channels) item - no VALU transposition and half the gather index math of tn_kernel_bf16 - and the
+//   MFMA operands (8 consecutive pixels of one channel per lane) come out of the LDS read path already transposed:
+//   lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block and lane i receives column i.
+//   128 x 128 tiles, Ca % 8 == 0, Cb % 8 == 0; everything else as tn_kernel_bf16.
+// ------------------------------------------------------------------------------------------
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+// 4 rows x 16 columns of 16-bit elements, delivered column-major: lane i of a 16-lane group gets column i
+__device__ __forceinline__ s16x4_t lds_read_tr16(uint32_t lds_byte_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4_t*>(lds_byte_addr));
+}
+
+__device__ __forceinline__ int tr_swz_off(int row, int chunk) {
+    return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void tn_kernel_bf16_tr(const TNParams p) {
+    constexpr int TM = 2, TN = 2, WN = 2, BM = 128, BN = 128;
+    constexpr int TILE_B = BKB * 256;                 // bytes of one [32][128] bf16 image
+    __shared__ __attribute__((aligned(16))) unsigned char Ap[2][TILE_B];
+    __shared__ __attribute__((aligned(16))) unsigned char Bp[2][TILE_B];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const Gather& g = p.g;
+
+    int tile, bz = blockIdx.z;
+    if (p.zfold > 0) {
+        const int ntile = p.tiles_m * p.tiles_n;
+        const int lin = xcd_remap(blockIdx.x, ntile * p.zfold);
+        bz = lin / ntile;
+        tile = lin - bz * ntile;
+    } else {
+        tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    }
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    const int mf0 = tile_m * BM, cb0 = tile_n * BN;
+    const int zb = bz / p.splitk, zs = bz % p.splitk;
+    const float* Abase = p.A + (int64_t)zb * p.strideA;
+    const float* Bbase = p.Bv + (int64_t)zb * p.strideB;
+
+    const int row_begin = zs * p.rows_per_split;
+    const int row_end = min(p.M, row_begin + p.rows_per_split);
+    const int niter = max(0, (row_end - row_begin + BKB - 1) / BKB);
+
+    // staging items: idx = t + 256 i -> pixel idx >> 4 of the K tile, 16-byte chunk idx & 15 (8 channels)
+    int a_kh[2], a_kw[2], a_c[2], b_c[2], st_off[2], pix[2];
+    RowPos apos[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = t + 256 * i;
+        const int chunk = idx & 15;
+        pix[i] = idx >> 4;
+        const int mf = mf0 + chunk * 8;
+        int tap = 0, c = mf;
+        if (MODE != GATHER_PLAIN) {
+            tap = mf / p.Ca;
+            c = mf - tap * p.Ca;
+        }
+        a_kh[i] = tap / g.k;
+        a_kw[i] = tap % g.k;
+        a_c[i] = mf < p.Mf ? c : -1;
+        b_c[i] = cb0 + chunk * 8;
+        st_off[i] = tr_swz_off(pix[i], chunk);
+        apos[i] = decompose_row<MODE>(g, row_begin + pix[i], p.M, 0, 0);
+    }
+
+    float4 ra[2][2], rb[2][2];
+    int l_row = row_begin;
+
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = l_row + pix[i];
+            RowPos rp = apos[i];
+            rp.valid = m < p.M;
+            if (MODE == GATHER_PLAIN) {
+                apos[i].b += BKB;
+            } else {
+                apos[i].wo += BKB;
+                while (apos[i].wo >= g.Wq) {
+                    apos[i].wo -= g.Wq;
+                    if (++apos[i].ho == g.Hq) {
+                        apos[i].ho = 0;
+                        ++apos[i].b;
+                    }
+                }
+            }
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            if (a_c[i] >= 0 && m < row_end) {
+                int64_t off[1];
+                tap_sources<MODE, false>(g, rp, a_kh[i], a_kw[i], off);
+                v0 = load_chan4<true>(Abase, off[0], a_c[i], p.Ca);
+                v1 = load_chan4<true>(Abase, off[0], a_c[i] + 4, p.Ca);
+            }
+            ra[i][0] = v0;
+            ra[i][1] = v1;
+            float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+            if (m < row_end) {
+                w0 = load_chan4<true>(Bbase, (int64_t)m * p.b_ld, b_c[i], p.Cb);
+                w1 = load_chan4<true>(Bbase, (int64_t)m * p.b_ld, b_c[i] + 4, p.Cb);
+            }
+            rb[i][0] = w0;
+            rb[i][1] = w1;
+        }
+        l_row += BKB;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<bf16x8*>(Ap[buf] + st_off[i]) = cvt8(ra[i][0], ra[i][1]);
+            *reinterpret_cast<bf16x8*>(Bp[buf] + st_off[i]) = cvt8(rb[i][0], rb[i][1]);
+        }
+    };
+
+    floatx16_b acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (niter > 0) {
+        load_tile();
+        store_tile(0);
+    }
+    __syncthreads();
+
+    // transposed-read addresses (buffer 0, k-step 0): lane -> k block lane >> 5, 16-channel group (lane >> 4) & 1,
+    // block row q = (lane & 15) >> 2, column quad pq = lane & 3; read jj covers pixels 8 kblk + 4 jj .. + 3
+    const int kblk = lane >> 5, g16 = (lane >> 4) & 1, q = (lane & 15) >> 2, pq = lane & 3;
+    const uint32_t a_lds = static_cast<uint32_t>(
+        reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)&Ap[0][0]));
+    const uint32_t b_lds = static_cast<uint32_t>(
+        reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)&Bp[0][0]));
+    uint32_t a_ad[TM][2], b_ad[TN][2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int row = 8 * kblk + 4 * jj + q;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            a_ad[i][jj] = a_lds + tr_swz_off(row, 4 * (wm * TM + i) + 2 * g16 + (pq >> 1)) + 8 * (pq & 1);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            b_ad[j][jj] = b_lds + tr_swz_off(row, 4 * (wn * TN + j) + 2 * g16 + (pq >> 1)) + 8 * (pq & 1);
+    }
+
+    auto operand = [&](uint32_t lo_addr, uint32_t hi_addr) {
+        const s16x4_t lo = lds_read_tr16(lo_addr), hi = lds_read_tr16(hi_addr);
+        const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto mma = [&](uint32_t bufoff) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = operand(a_ad[i][0] + bufoff + 4096 * s, a_ad[i][1] + bufoff + 4096 * s);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = operand(b_ad[j][0] + bufoff + 4096 * s, b_ad[j][1] + bufoff + 4096 * s);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    for (int it = 0; it < niter; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < niter) load_tile();
+        mma(cur ? (uint32_t)TILE_B : 0u);
+        if (it + 1 < niter) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    const float alpha = p.alpha ? *p.alpha : 1.0f;
+    float* obase = p.out + (int64_t)zb * p.strideC + (int64_t)zs * p.slab_stride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mf0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= p.Mf) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = cb0 + wn * 32 * TN + 32 * j + (lane & 31);
+                if (col < p.Cb) obase[(int64_t)row * p.out_ld + col] = acc[i][j][r] * alpha;
+            }
+        }
+    }
+}
+
+
 }  // namespace bg
