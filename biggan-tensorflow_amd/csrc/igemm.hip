@@ -750,6 +750,13 @@ static void launch_nn_tile(NNParams& p, const NNPlan& pl, bool vec, bool bf16, i
             return;
         }
     }
+    if constexpr (!BT) {
+        static const int nn_btr = getenv("BG_NN_BTR") ? atoi(getenv("BG_NN_BTR")) : 1;   // weights read through ds_read_b64_tr_b16
+        if (nn_btr && bf16 && vec && pl.bm == 128 && pl.bn == 128) {
+            hipLaunchKernelGGL((nn_kernel_bf16<2, 2, false, MODE, MIRROR, false, true>), grid, dim3(256), 0, s, p);
+            return;
+        }
+    }
     if (bf16 && vec && pl.bn >= 64) {
         if (pl.bm == 128 && pl.bn == 128)
             hipLaunchKernelGGL((nn_kernel_bf16<2, 2, BT, MODE, MIRROR>), grid, dim3(256), 0, s, p);

@@ -33,6 +33,19 @@ __device__ __forceinline__ bf16x4 cvt4(float a, float b, float c, float d) {
     return r;
 }
 
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+// 4 rows x 16 columns of 16-bit elements, delivered column-major: lane i of a 16-lane group gets column i
+__device__ __forceinline__ s16x4_t lds_read_tr16(uint32_t lds_byte_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4_t*>(lds_byte_addr));
+}
+
+__device__ __forceinline__ int tr_swz_off(int row, int chunk) {
+    return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
 // TM x TN MFMA tiles over one 32-deep K tile: 2 k-steps of 16
 template <int TM, int TN>
 __device__ __forceinline__ void mma_tile_bf16(const __bf16* __restrict__ as, const __bf16* __restrict__ bs, int a_rd,
@@ -57,8 +70,11 @@ __device__ __forceinline__ void mma_tile_bf16(const __bf16* __restrict__ as, con
 // ------------------------------------------------------------------------------------------
 // SRC16: both operands are read from bf16 copies (p.A16 / p.B16, same element offsets as the fp32 tensors):
 // half the L2 -> LDS bytes per tile and no conversion in the loop.  Requires C % 8 == 0, N % 8 == 0, !MIRROR.
-template <int TM, int TN, bool BT, int MODE, bool MIRROR, bool SRC16 = false>
+// BTR (only !BT, TN == 2): the [k][n] weight tile stays k-major in LDS (32 rows of 128 bf16, swizzled like the wgrad
+// kernel's images) and the B operand is read through ds_read_b64_tr_b16 instead of being transposed by the staging code.
+template <int TM, int TN, bool BT, int MODE, bool MIRROR, bool SRC16 = false, bool BTR = false>
 __global__ __launch_bounds__(256) void nn_kernel_bf16(const NNParams p) {
+    static_assert(!BTR || (!BT && TN == 2 && !SRC16), "BTR: non-BT weights, 128-wide tile, fp32 sources");
     constexpr int WN = 2;
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AITEMS = BM * 4 / 256;            // (row, k8) items per thread
@@ -222,6 +238,21 @@ __global__ __launch_bounds__(256) void nn_kernel_bf16(const NNParams p) {
                     rb[i * 2 + hlf] = v;
                 }
             }
+        } else if (BTR) {
+            // items: k row (t + 256 i) >> 4, 16-byte chunk (t + 256 i) & 15 = 8 consecutive n: coalesced along n
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = t + 256 * i;
+                const int c = c0 + (idx >> 4), n = n0 + (idx & 15) * 8;
+                float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                if (c < p.C) {
+                    const float* src = wt + (int64_t)c * p.ldk + n;
+                    if (n < p.N) v0 = ld4(src);
+                    if (n + 4 < p.N) v1 = ld4(src + 4);
+                }
+                rb[i * 2] = v0;
+                rb[i * 2 + 1] = v1;
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < BITEMS_N; ++i) {
@@ -301,6 +332,13 @@ __global__ __launch_bounds__(256) void nn_kernel_bf16(const NNParams p) {
                 const int n = (t >> 2) + 64 * i;
                 *reinterpret_cast<bf16x8*>(bs + n * LROW + a_k8) = cvt8(rb[i * 2], rb[i * 2 + 1]);
             }
+        } else if (BTR) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = t + 256 * i;
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned char*>(bs) + tr_swz_off(idx >> 4, idx & 15)) =
+                    cvt8(rb[i * 2], rb[i * 2 + 1]);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < BITEMS_N; ++i) {
@@ -335,11 +373,45 @@ __global__ __launch_bounds__(256) void nn_kernel_bf16(const NNParams p) {
     // operand reads: lane l -> row (l & 31), k offset 8 * (l >> 5)
     const int a_rd = (wm * 32 * TM + (lane & 31)) * LROW + (lane >> 5) * 8;
     const int b_rd = (wn * 32 * TN + (lane & 31)) * LROW + (lane >> 5) * 8;
+    uint32_t btr_ad[TN][2];
+    if constexpr (BTR) {
+        const int kblk = lane >> 5, g16 = (lane >> 4) & 1, q = (lane & 15) >> 2, pq = lane & 3;
+        const uint32_t b_lds = static_cast<uint32_t>(
+            reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)&Bs[0][0]));
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                btr_ad[j][jj] = b_lds + tr_swz_off(8 * kblk + 4 * jj + q, 4 * (wn * TN + j) + 2 * g16 + (pq >> 1)) +
+                                8 * (pq & 1);
+    }
 
     for (int it = 0; it < niter; ++it) {
         const int cur = it & 1;
         if (it + 1 < niter) load_tile();
-        mma_tile_bf16<TM, TN>(As[cur], Bs[cur], a_rd, b_rd, acc);
+        if constexpr (BTR) {
+#pragma unroll
+            for (int s2 = 0; s2 < BKB / 16; ++s2) {
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[i] = *reinterpret_cast<const bf16x8*>(As[cur] + a_rd + 32 * i * LROW + s2 * 16);
+                const uint32_t boff = (uint32_t)cur * (uint32_t)(BN * LROW * 2) + 4096u * s2;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const s16x4_t lo = lds_read_tr16(btr_ad[j][0] + boff), hi = lds_read_tr16(btr_ad[j][1] + boff);
+                    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    b[j] = __builtin_bit_cast(bf16x8, v);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            mma_tile_bf16<TM, TN>(As[cur], Bs[cur], a_rd, b_rd, acc);
+        }
         if (it + 1 < niter) store_tile(cur ^ 1);
         __syncthreads();
     }
@@ -561,19 +633,6 @@ __global__ __launch_bounds__(256) void tn_kernel_bf16(const TNParams p) {
 //   lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block and lane i receives column i.
 //   128 x 128 tiles, Ca % 8 == 0, Cb % 8 == 0; everything else as tn_kernel_bf16.
 // ------------------------------------------------------------------------------------------
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-typedef short s16x8_t __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
-
-// 4 rows x 16 columns of 16-bit elements, delivered column-major: lane i of a 16-lane group gets column i
-__device__ __forceinline__ s16x4_t lds_read_tr16(uint32_t lds_byte_addr) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4_t*>(lds_byte_addr));
-}
-
-__device__ __forceinline__ int tr_swz_off(int row, int chunk) {
-    return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256) void tn_kernel_bf16_tr(const TNParams p) {
     constexpr int TM = 2, TN = 2, WN = 2, BM = 128, BN = 128;
