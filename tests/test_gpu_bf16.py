@@ -56,7 +56,9 @@ def test_bf16_source_kernels_equal_staged_rounding():
 
 
 @pytest.mark.parametrize("N,H,Cin,Cout,k,s", [(2, 16, 64, 128, 3, 1), (2, 16, 64, 64, 3, 2), (4, 8, 128, 256, 3, 1),
-                                              (2, 32, 64, 64, 3, 1), (3, 8, 96, 192, 3, 2), (16, 4, 256, 256, 3, 1)])
+                                              (2, 32, 64, 64, 3, 1), (3, 8, 96, 192, 3, 2), (16, 4, 256, 256, 3, 1),
+                                              (4, 16, 128, 96, 3, 1),      # 128-wide tile, ragged N = 96 (ch = 96 nets)
+                                              (4, 16, 160, 200, 3, 1)])    # ragged N = 200 and Ca = 160 in the wgrad
 def test_conv_bf16(bf16_mode, N, H, Cin, Cout, k, s):
     from biggan_tensorflow_amd import functional as Fn, hip
     rng = np.random.default_rng(N + H + Cin + Cout)
@@ -77,7 +79,8 @@ def test_conv_bf16(bf16_mode, N, H, Cin, Cout, k, s):
 
 
 @pytest.mark.parametrize("N,H,Cin,Cout,k,s", [(2, 8, 128, 64, 4, 2), (2, 8, 64, 64, 3, 1), (2, 4, 256, 128, 4, 2),
-                                              (2, 16, 96, 96, 3, 1), (8, 4, 192, 192, 4, 2)])
+                                              (2, 16, 96, 96, 3, 1), (8, 4, 192, 192, 4, 2),
+                                              (4, 16, 96, 128, 4, 2)])     # dgrad: 128-wide tile over N = Cin = 96
 def test_deconv_bf16(bf16_mode, N, H, Cin, Cout, k, s):
     from biggan_tensorflow_amd import functional as Fn
     rng = np.random.default_rng(N + H + Cin + Cout + k)
