@@ -806,6 +806,415 @@ __global__ __launch_bounds__(EW_BLOCK) void tanh_bwd_kernel(const float* __restr
         dx[i] = dy[i] * (1.f - y[i] * y[i]);
 }
 
+
+// ==========================================================================================
+// Typed variants for the bf16-resident data path (BASELINE configs 3-5): the same arithmetic in fp32 registers,
+// activation tensors fp32 or bf16 in HBM (8-byte bf16x4 / 16-byte float4 accesses per thread).
+// ==========================================================================================
+template <int VEC>
+__device__ __forceinline__ void loadv(const __bf16* p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const uint2 r = *reinterpret_cast<const uint2*>(p);
+        v[0] = __builtin_bit_cast(float, r.x << 16);
+        v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+        v[2] = __builtin_bit_cast(float, r.y << 16);
+        v[VEC - 1] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = (float)p[j];
+    }
+}
+__device__ __forceinline__ uint32_t bf16_pack2(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+template <int VEC>
+__device__ __forceinline__ void storev(float* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4)
+        stg4(p, make_float4(v[0], v[1], v[2], v[VEC - 1]));
+    else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) p[j] = v[j];
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void storev(__bf16* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        uint2 r;
+        r.x = bf16_pack2(v[0], v[1]);
+        r.y = bf16_pack2(v[2], v[VEC - 1]);
+        *reinterpret_cast<uint2*>(p) = r;
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) p[j] = (__bf16)v[j];
+    }
+}
+
+template <class TX, class TY>
+__global__ __launch_bounds__(EW_BLOCK) void cast_kernel(const TX* __restrict__ x, TY* __restrict__ y, int64_t n) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+        float v[4];
+        loadv<4>(x + i * 4, v);
+        storev<4>(y + i * 4, v);
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK)
+        y[i] = (TY)(float)x[i];
+}
+
+template <class TX>
+struct BnStatsFnT {
+    const TX* x;
+    int C;
+    template <int VEC>
+    __device__ __forceinline__ void operator()(int, int64_t r, int c, float (&acc)[2][VEC]) const {
+        float v[VEC];
+        loadv<VEC>(x + r * C + c, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            acc[0][j] += v[j];
+            acc[1][j] += v[j] * v[j];
+        }
+    }
+};
+
+template <int VEC, class TX, class TY>
+__global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_fwd_t_kernel(const TX* __restrict__ x,
+                                                                       const float* __restrict__ mean,
+                                                                       const float* __restrict__ rstd,
+                                                                       const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, int per_sample,
+                                                                       const float* __restrict__ alpha,
+                                                                       TY* __restrict__ y, int N, int HW, int C) {
+    const int CV = C / VEC;
+    const int64_t total = (int64_t)N * HW * CV;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c = (int)(i % CV) * VEC;
+        const int n = (int)(i / ((int64_t)HW * CV));
+        const float* gp = gamma + (per_sample ? (int64_t)n * C : 0) + c;
+        const float* bp = beta + (per_sample ? (int64_t)n * C : 0) + c;
+        float xv[VEC], mu[VEC], rs[VEC], ga[VEC], be[VEC], al[VEC], out[VEC];
+        loadv<VEC>(x + i * VEC, xv);
+        loadv<VEC>(mean + c, mu);
+        loadv<VEC>(rstd + c, rs);
+        loadv<VEC>(gp, ga);
+        loadv<VEC>(bp, be);
+        if (alpha) loadv<VEC>(alpha + c, al);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float inv = rs[j] * ga[j];
+            float v = xv[j] * inv + (be[j] - mu[j] * inv);
+            out[j] = alpha ? prelu_f(v, al[j]) : v;
+        }
+        storev<VEC>(y + i * VEC, out);
+    }
+}
+
+template <class TX, class TY>
+struct BnBwdReduceFnT {
+    const TX* x;
+    const TY* dy;
+    const float *mean, *rstd, *gamma, *beta, *alpha;
+    int per_sample, HW, C;
+    template <int VEC>
+    __device__ __forceinline__ void operator()(int n, int64_t r, int c, float (&acc)[3][VEC]) const {
+        const int64_t off = ((int64_t)n * HW + r) * C + c;
+        float xv[VEC], dv[VEC], mu[VEC], rs[VEC], ga[VEC], be[VEC], al[VEC];
+        loadv<VEC>(x + off, xv);
+        loadv<VEC>(dy + off, dv);
+        loadv<VEC>(mean + c, mu);
+        loadv<VEC>(rstd + c, rs);
+        loadv<VEC>(gamma + (per_sample ? (int64_t)n * C : 0) + c, ga);
+        loadv<VEC>(beta + (per_sample ? (int64_t)n * C : 0) + c, be);
+        if (alpha) loadv<VEC>(alpha + c, al);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xh = (xv[j] - mu[j]) * rs[j];
+            const float pre = xh * ga[j] + be[j];
+            const float g = alpha ? dv[j] * prelu_d(pre, al[j]) : dv[j];
+            acc[0][j] += g;
+            acc[1][j] += g * xh;
+            acc[2][j] += alpha ? dv[j] * fminf(pre, 0.f) : 0.f;
+        }
+    }
+};
+
+template <int VEC, class TX, class TY>
+__global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_bwd_dx_t_kernel(
+    const TX* __restrict__ x, const TY* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta, int per_sample,
+    const float* __restrict__ alpha, const float* __restrict__ cm, TX* __restrict__ dx, int N, int HW, int C) {
+    const int CV = C / VEC;
+    const int64_t total = (int64_t)N * HW * CV;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c = (int)(i % CV) * VEC;
+        const int n = (int)(i / ((int64_t)HW * CV));
+        float xv[VEC], dv[VEC], mu[VEC], rs[VEC], ga[VEC], be[VEC], al[VEC], m1[VEC], m2[VEC], out[VEC];
+        loadv<VEC>(x + i * VEC, xv);
+        loadv<VEC>(dy + i * VEC, dv);
+        loadv<VEC>(mean + c, mu);
+        loadv<VEC>(rstd + c, rs);
+        loadv<VEC>(gamma + (per_sample ? (int64_t)n * C : 0) + c, ga);
+        loadv<VEC>(beta + (per_sample ? (int64_t)n * C : 0) + c, be);
+        loadv<VEC>(cm + c, m1);
+        loadv<VEC>(cm + C + c, m2);
+        if (alpha) loadv<VEC>(alpha + c, al);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xh = (xv[j] - mu[j]) * rs[j];
+            const float pre = xh * ga[j] + be[j];
+            const float g = alpha ? dv[j] * prelu_d(pre, al[j]) : dv[j];
+            out[j] = rs[j] * (g * ga[j] - m1[j] - xh * m2[j]);
+        }
+        storev<VEC>(dx + i * VEC, out);
+    }
+}
+
+template <int VEC, class TX, class TY>
+__global__ __launch_bounds__(EW_BLOCK) void prelu_fwd_t_kernel(const TX* __restrict__ x, const float* __restrict__ alpha,
+                                                                TY* __restrict__ y, int64_t total_v, int C) {
+    const int CV = C / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total_v; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c = (int)(i % CV) * VEC;
+        float xv[VEC], al[VEC], out[VEC];
+        loadv<VEC>(x + i * VEC, xv);
+        loadv<VEC>(alpha + c, al);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) out[j] = prelu_f(xv[j], al[j]);
+        storev<VEC>(y + i * VEC, out);
+    }
+}
+
+template <int VEC, class TX, class TY>
+__global__ __launch_bounds__(EW_BLOCK) void prelu_bwd_dx_t_kernel(const TX* __restrict__ x, const TY* __restrict__ dy,
+                                                                   const float* __restrict__ alpha, TX* __restrict__ dx,
+                                                                   int64_t total_v, int C) {
+    const int CV = C / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total_v; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c = (int)(i % CV) * VEC;
+        float xv[VEC], dv[VEC], al[VEC], out[VEC];
+        loadv<VEC>(x + i * VEC, xv);
+        loadv<VEC>(dy + i * VEC, dv);
+        loadv<VEC>(alpha + c, al);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) out[j] = dv[j] * prelu_d(xv[j], al[j]);
+        storev<VEC>(dx + i * VEC, out);
+    }
+}
+
+template <class TX, class TY>
+struct PreluDalphaFnT {
+    const TX* x;
+    const TY* dy;
+    int C;
+    template <int VEC>
+    __device__ __forceinline__ void operator()(int, int64_t r, int c, float (&acc)[1][VEC]) const {
+        float xv[VEC], dv[VEC];
+        loadv<VEC>(x + r * C + c, xv);
+        loadv<VEC>(dy + r * C + c, dv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[0][j] += dv[j] * fminf(xv[j], 0.f);
+    }
+};
+
+template <class T>
+struct BiasGradFnT {
+    const T* dy;
+    int C;
+    template <int VEC>
+    __device__ __forceinline__ void operator()(int, int64_t r, int c, float (&acc)[1][VEC]) const {
+        float dv[VEC];
+        loadv<VEC>(dy + r * C + c, dv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[0][j] += dv[j];
+    }
+};
+
+template <int VEC, class T>
+__global__ __launch_bounds__(EW_BLOCK) void maxpool2_fwd_t_kernel(const T* __restrict__ x, T* __restrict__ y, int N,
+                                                                   int H, int W, int C) {
+    const int CV = C / VEC, Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)N * Ho * Wo * CV;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int cv = (int)(i % CV);
+        int64_t t = i / CV;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const T* p = x + (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + cv * VEC;
+        float a[VEC], b[VEC], c_[VEC], d[VEC], o[VEC];
+        loadv<VEC>(p, a);
+        loadv<VEC>(p + C, b);
+        loadv<VEC>(p + (int64_t)W * C, c_);
+        loadv<VEC>(p + (int64_t)W * C + C, d);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(c_[j], d[j]));
+        storev<VEC>(y + i * VEC, o);
+    }
+}
+
+template <int VEC, class T>
+__global__ __launch_bounds__(EW_BLOCK) void maxpool2_bwd_t_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                   T* __restrict__ dx, int N, int H, int W, int C) {
+    const int CV = C / VEC, Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)N * Ho * Wo * CV;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int cv = (int)(i % CV);
+        int64_t t = i / CV;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const int64_t base = (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + cv * VEC;
+        const int64_t o1 = C, o2 = (int64_t)W * C, o3 = (int64_t)W * C + C;
+        float a[VEC], b[VEC], c_[VEC], d[VEC], g[VEC];
+        loadv<VEC>(x + base, a);
+        loadv<VEC>(x + base + o1, b);
+        loadv<VEC>(x + base + o2, c_);
+        loadv<VEC>(x + base + o3, d);
+        loadv<VEC>(dy + i * VEC, g);
+        float ra[VEC], rb[VEC], rc[VEC], rd[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float m = fmaxf(fmaxf(a[j], b[j]), fmaxf(c_[j], d[j]));
+            const bool sa = a[j] == m;
+            const bool sb = !sa && b[j] == m;
+            const bool sc = !sa && !sb && c_[j] == m;
+            const bool sd = !sa && !sb && !sc;
+            ra[j] = sa ? g[j] : 0.f;
+            rb[j] = sb ? g[j] : 0.f;
+            rc[j] = sc ? g[j] : 0.f;
+            rd[j] = sd ? g[j] : 0.f;
+        }
+        storev<VEC>(dx + base, ra);
+        storev<VEC>(dx + base + o1, rb);
+        storev<VEC>(dx + base + o2, rc);
+        storev<VEC>(dx + base + o3, rd);
+    }
+}
+
+// y[n][c] = sum_hw x[n][hw][c]: one thread per (n, 4 channels), the HW rows streamed with 4 loads in flight
+template <int VEC, class TX>
+__global__ __launch_bounds__(EW_BLOCK) void sum_pool_fwd_t_kernel(const TX* __restrict__ x, float* __restrict__ y, int N,
+                                                                   int HW, int C) {
+    const int CV = C / VEC;
+    const int64_t total = (int64_t)N * CV;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int cv = (int)(i % CV);
+        const int n = (int)(i / CV);
+        float s[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+        for (int r = 0; r < HW; ++r) {
+            float v[VEC];
+            loadv<VEC>(x + ((int64_t)n * HW + r) * C + cv * VEC, v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s[j] += v[j];
+        }
+        storev<VEC>(y + (int64_t)n * C + cv * VEC, s);
+    }
+}
+
+template <int VEC, class TX>
+__global__ __launch_bounds__(EW_BLOCK) void sum_pool_bwd_t_kernel(const float* __restrict__ dy, TX* __restrict__ dx,
+                                                                   int N, int HW, int C) {
+    const int CV = C / VEC;
+    const int64_t total = (int64_t)N * HW * CV;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int cv = (int)(i % CV);
+        const int n = (int)(i / ((int64_t)HW * CV));
+        float v[VEC];
+        loadv<VEC>(dy + (int64_t)n * C + cv * VEC, v);
+        storev<VEC>(dx + i * VEC, v);
+    }
+}
+
+// y = sa * a + sb * b (sa, sb: host scalars or device scalars when the pointers are non-null), n % 4 == 0
+template <class T>
+__global__ __launch_bounds__(EW_BLOCK) void lincomb_t_kernel(const T* __restrict__ a, const float* sa_dev, float sa,
+                                                              const T* __restrict__ b, float sb, T* __restrict__ y,
+                                                              int64_t n4) {
+    const float s = sa_dev ? *sa_dev : sa;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+        float av[4], bv[4], o[4];
+        loadv<4>(a + i * 4, av);
+        if (b) {
+            loadv<4>(b + i * 4, bv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = s * av[j] + sb * bv[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = s * av[j];
+        }
+        storev<4>(y + i * 4, o);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(EW_BLOCK) void dot_t_kernel(const T* __restrict__ a, const T* __restrict__ b, float* out,
+                                                          int64_t n4) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+        float av[4], bv[4];
+        loadv<4>(a + i * 4, av);
+        loadv<4>(b + i * 4, bv);
+        s += av[0] * bv[0] + av[1] * bv[1] + av[2] * bv[2] + av[3] * bv[3];
+    }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+// w / sigma for one [taps][R][Cc] weight plus its two bf16 packed copies (BgSnItem::pack_p / pack_t): 64 x 64 tiles
+// of one tap through LDS so that both copies are written in 128-byte row segments
+__device__ __forceinline__ void sn_normalize_pack_body(const float* __restrict__ w, float sigma,
+                                                       float* __restrict__ wn, __bf16* __restrict__ pp,
+                                                       __bf16* __restrict__ pt, int taps, int R, int Cc, int bid,
+                                                       int nblocks, float (*tile)[65]) {
+    const int tr = (R + 63) / 64, tc = (Cc + 63) / 64;
+    const int ntiles = taps * tr * tc;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 element pairs x 8 rows per pass
+    for (int tl = bid; tl < ntiles; tl += nblocks) {
+        const int tap = tl / (tr * tc);
+        const int rem = tl - tap * (tr * tc);
+        const int r0 = (rem / tc) * 64, c0 = (rem % tc) * 64;
+        const int64_t base = (int64_t)tap * R * Cc;
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int r = r0 + ty + 8 * ps, c = c0 + 2 * tx;
+            float v0 = 0.f, v1 = 0.f;
+            if (r < R && c < Cc) {            // Cc is even on this path
+                const float2 wv = *reinterpret_cast<const float2*>(w + base + (int64_t)r * Cc + c);
+                v0 = wv.x / sigma;
+                v1 = wv.y / sigma;
+                if (wn) *reinterpret_cast<float2*>(wn + base + (int64_t)r * Cc + c) = make_float2(v0, v1);
+                *reinterpret_cast<uint32_t*>(pp + base + (int64_t)r * Cc + c) = bf16_pack2(v0, v1);
+            }
+            tile[ty + 8 * ps][2 * tx] = v0;
+            tile[ty + 8 * ps][2 * tx + 1] = v1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int c = c0 + ty + 8 * ps, r = r0 + 2 * tx;
+            if (c < Cc && r < R)              // R is even on this path
+                *reinterpret_cast<uint32_t*>(pt + base + (int64_t)c * R + r) =
+                    bf16_pack2(tile[2 * tx][ty + 8 * ps], tile[2 * tx + 1][ty + 8 * ps]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void weight_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ pp,
+                                                                __bf16* __restrict__ pt, int taps, int R, int Cc) {
+    __shared__ float tile[64][65];
+    sn_normalize_pack_body(w, 1.0f, nullptr, pp, pt, taps, R, Cc, blockIdx.x, gridDim.x, tile);
+}
+
 // ------------------------------------------------------------------------------------------
 // spectral norm (ops.py:718-747)
 // scratch layout (floats): [0]=sum v_^2, [1]=sigma, [2]=rs_v, [3]=<G,Wn>; [4 .. 4+rows) = v_ ; then cols of u_raw
@@ -1008,9 +1417,20 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_batch_finalize_kernel(const BgSnI
 }
 
 __global__ __launch_bounds__(EW_BLOCK) void sn_batch_normalize_kernel(const BgSnItem* __restrict__ items, char* ws) {
+    __shared__ float tile[64][65];
     const BgSnItem it = items[blockIdx.y];
     double* scr = sn_scr(it, ws);
     const float* vraw = reinterpret_cast<const float*>(scr + 4 + it.cols);
+    if (it.pack_p) {
+        // conv / transposed-conv kernel of the bf16-resident path: w / sigma in fp32 plus the two bf16 packed copies
+        sn_normalize_pack_body(it.w, (float)scr[1], it.w_norm, reinterpret_cast<__bf16*>(it.pack_p),
+                               reinterpret_cast<__bf16*>(it.pack_t), it.taps, it.rows / it.taps, it.cols, blockIdx.x,
+                               gridDim.x, tile);
+        const float rs_v = (float)scr[2];
+        for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < it.rows; i += (int64_t)gridDim.x * EW_BLOCK)
+            it.v[i] = vraw[i] * rs_v;
+        return;
+    }
     sn_normalize_body(it.w, scr, vraw, it.w_norm, it.v, (int64_t)it.rows * it.cols, it.rows, blockIdx.x, gridDim.x);
 }
 
@@ -1579,6 +1999,236 @@ int bg_adam_tf_ema_step_dev(float* p, const float* g, float* m, float* v, float*
     BG_REQUIRE(p && g && m && v && lr_t_dev && n > 0, "bg_adam_tf_ema_step_dev: bad argument");
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, as_stream(stream), p, g, m, v, ema, 0.f,
                        lr_t_dev, b1, b2, eps, ema_decay, grad_scale, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// "_t" entry points: activation tensors fp32 or bf16 (BG_F32 / BG_BF16), parameters and statistics fp32
+// ------------------------------------------------------------------------------------------
+#define BG_DT_OK(d) ((d) == BG_F32 || (d) == BG_BF16)
+// run EXPR with TX / TY bound to the element types named by (xd, yd)
+#define BG_DISPATCH_XY(xd, yd, ...)                                          \
+    do {                                                                     \
+        if ((xd) == BG_F32 && (yd) == BG_F32) {                              \
+            using TX = float; using TY = float; __VA_ARGS__;                 \
+        } else if ((xd) == BG_F32) {                                         \
+            using TX = float; using TY = __bf16; __VA_ARGS__;                \
+        } else if ((yd) == BG_F32) {                                         \
+            using TX = __bf16; using TY = float; __VA_ARGS__;                \
+        } else {                                                             \
+            using TX = __bf16; using TY = __bf16; __VA_ARGS__;               \
+        }                                                                    \
+    } while (0)
+#define BG_DISPATCH_T(d, ...)                                                \
+    do {                                                                     \
+        if ((d) == BG_F32) { using T = float; __VA_ARGS__; }                 \
+        else { using T = __bf16; __VA_ARGS__; }                              \
+    } while (0)
+
+int bg_cast(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, void* stream) {
+    BG_REQUIRE(x && y && n > 0 && BG_DT_OK(x_dtype) && BG_DT_OK(y_dtype), "bg_cast: bad argument");
+    BG_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "bg_cast: tensors must be 16-byte aligned");
+    BG_DISPATCH_XY(x_dtype, y_dtype,
+                   hipLaunchKernelGGL((cast_kernel<TX, TY>), dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                      (const TX*)x, (TY*)y, n));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_weight_pack(const float* w, int taps, int rows_per_tap, int cols, void* pack_p, void* pack_t, void* stream) {
+    BG_REQUIRE(w && pack_p && pack_t && taps > 0 && rows_per_tap > 0 && cols > 0, "bg_weight_pack: bad argument");
+    BG_REQUIRE(rows_per_tap % 2 == 0 && cols % 2 == 0, "bg_weight_pack: inner dimensions must be even");
+    const int tiles = taps * ((rows_per_tap + 63) / 64) * ((cols + 63) / 64);
+    hipLaunchKernelGGL(weight_pack_kernel, dim3(tiles < 2048 ? tiles : 2048), dim3(EW_BLOCK), 0, as_stream(stream), w,
+                       (__bf16*)pack_p, (__bf16*)pack_t, taps, rows_per_tap, cols);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_bn_stats_t(const void* x, int x_dtype, double* sums, int64_t rows, int C, void* stream) {
+    BG_REQUIRE(x && sums && rows > 0 && C > 0 && BG_DT_OK(x_dtype), "bg_bn_stats_t: bad argument");
+    BG_DISPATCH_T(x_dtype, BnStatsFnT<T> fn{(const T*)x, C};
+                  launch_colreduce<2>(fn, sums, (int64_t)C, rows, 1, C, as_stream(stream)));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_bn_apply_act_fwd_t(const void* x, int x_dtype, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int per_sample, const float* alpha, void* y, int y_dtype, int N, int HW,
+                          int C, void* stream) {
+    BG_REQUIRE(x && mean && rstd && gamma && beta && y && N > 0 && HW > 0 && C > 0 && BG_DT_OK(x_dtype) && BG_DT_OK(y_dtype),
+               "bg_bn_apply_act_fwd_t: bad argument");
+    const int64_t total = (int64_t)N * HW * C;
+    if (C % 4 == 0)
+        BG_DISPATCH_XY(x_dtype, y_dtype,
+                       hipLaunchKernelGGL((bn_apply_act_fwd_t_kernel<4, TX, TY>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK),
+                                          0, as_stream(stream), (const TX*)x, mean, rstd, gamma, beta, per_sample, alpha,
+                                          (TY*)y, N, HW, C));
+    else
+        BG_DISPATCH_XY(x_dtype, y_dtype,
+                       hipLaunchKernelGGL((bn_apply_act_fwd_t_kernel<1, TX, TY>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0,
+                                          as_stream(stream), (const TX*)x, mean, rstd, gamma, beta, per_sample, alpha,
+                                          (TY*)y, N, HW, C));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_bn_apply_act_bwd_reduce_t(const void* x, int x_dtype, const void* dy, int y_dtype, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, int per_sample,
+                                 const float* alpha, float* part, int N, int HW, int C, void* stream) {
+    BG_REQUIRE(x && dy && mean && rstd && gamma && beta && part && N > 0 && HW > 0 && C > 0 && BG_DT_OK(x_dtype) &&
+                   BG_DT_OK(y_dtype), "bg_bn_apply_act_bwd_reduce_t: bad argument");
+    if (hipMemsetAsync(part, 0, sizeof(float) * 3 * (size_t)N * C, as_stream(stream)) != hipSuccess) {
+        set_error("bg_bn_apply_act_bwd_reduce_t: memset failed");
+        return BG_ERR_LAUNCH;
+    }
+    BG_DISPATCH_XY(x_dtype, y_dtype,
+                   BnBwdReduceFnT<TX, TY> fn{(const TX*)x, (const TY*)dy, mean, rstd, gamma, beta, alpha, per_sample, HW, C};
+                   launch_colreduce<3>(fn, part, (int64_t)N * C, HW, N, C, as_stream(stream)));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_bn_apply_act_bwd_dx_t(const void* x, int x_dtype, const void* dy, int y_dtype, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, int per_sample, const float* alpha, const float* cm,
+                             void* dx, int N, int HW, int C, void* stream) {
+    BG_REQUIRE(x && dy && mean && rstd && gamma && beta && cm && dx && N > 0 && HW > 0 && C > 0 && BG_DT_OK(x_dtype) &&
+                   BG_DT_OK(y_dtype), "bg_bn_apply_act_bwd_dx_t: bad argument");
+    const int64_t total = (int64_t)N * HW * C;
+    if (C % 4 == 0)
+        BG_DISPATCH_XY(x_dtype, y_dtype,
+                       hipLaunchKernelGGL((bn_apply_act_bwd_dx_t_kernel<4, TX, TY>), dim3(ew_grid(total / 4)),
+                                          dim3(EW_BLOCK), 0, as_stream(stream), (const TX*)x, (const TY*)dy, mean, rstd,
+                                          gamma, beta, per_sample, alpha, cm, (TX*)dx, N, HW, C));
+    else
+        BG_DISPATCH_XY(x_dtype, y_dtype,
+                       hipLaunchKernelGGL((bn_apply_act_bwd_dx_t_kernel<1, TX, TY>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0,
+                                          as_stream(stream), (const TX*)x, (const TY*)dy, mean, rstd, gamma, beta,
+                                          per_sample, alpha, cm, (TX*)dx, N, HW, C));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_prelu_fwd_t(const void* x, int x_dtype, const float* alpha, void* y, int y_dtype, int64_t rows, int C,
+                   void* stream) {
+    BG_REQUIRE(x && alpha && y && rows > 0 && C > 0 && BG_DT_OK(x_dtype) && BG_DT_OK(y_dtype), "bg_prelu_fwd_t: bad argument");
+    const int64_t total = rows * C;
+    if (C % 4 == 0)
+        BG_DISPATCH_XY(x_dtype, y_dtype,
+                       hipLaunchKernelGGL((prelu_fwd_t_kernel<4, TX, TY>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK), 0,
+                                          as_stream(stream), (const TX*)x, alpha, (TY*)y, total / 4, C));
+    else
+        BG_DISPATCH_XY(x_dtype, y_dtype,
+                       hipLaunchKernelGGL((prelu_fwd_t_kernel<1, TX, TY>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0,
+                                          as_stream(stream), (const TX*)x, alpha, (TY*)y, total, C));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_prelu_bwd_t(const void* x, int x_dtype, const void* dy, int y_dtype, const float* alpha, void* dx, float* dalpha,
+                   int64_t rows, int C, void* stream) {
+    BG_REQUIRE(x && dy && alpha && rows > 0 && C > 0 && BG_DT_OK(x_dtype) && BG_DT_OK(y_dtype), "bg_prelu_bwd_t: bad argument");
+    const int64_t total = rows * C;
+    if (dx) {
+        if (C % 4 == 0)
+            BG_DISPATCH_XY(x_dtype, y_dtype,
+                           hipLaunchKernelGGL((prelu_bwd_dx_t_kernel<4, TX, TY>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK),
+                                              0, as_stream(stream), (const TX*)x, (const TY*)dy, alpha, (TX*)dx, total / 4,
+                                              C));
+        else
+            BG_DISPATCH_XY(x_dtype, y_dtype,
+                           hipLaunchKernelGGL((prelu_bwd_dx_t_kernel<1, TX, TY>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0,
+                                              as_stream(stream), (const TX*)x, (const TY*)dy, alpha, (TX*)dx, total, C));
+        BG_LAUNCH_CHECK();
+    }
+    if (dalpha) {
+        BG_DISPATCH_XY(x_dtype, y_dtype, PreluDalphaFnT<TX, TY> fn{(const TX*)x, (const TY*)dy, C};
+                       launch_colreduce<1>(fn, dalpha, 0, rows, 1, C, as_stream(stream)));
+        BG_LAUNCH_CHECK();
+    }
+    return BG_OK;
+}
+
+int bg_bias_grad_t(const void* dy, int dtype, float* db, int64_t rows, int C, void* stream) {
+    BG_REQUIRE(dy && db && rows > 0 && C > 0 && BG_DT_OK(dtype), "bg_bias_grad_t: bad argument");
+    if (hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, as_stream(stream)) != hipSuccess) {
+        set_error("bg_bias_grad_t: memset failed");
+        return BG_ERR_LAUNCH;
+    }
+    BG_DISPATCH_T(dtype, BiasGradFnT<T> fn{(const T*)dy, C}; launch_colreduce<1>(fn, db, 0, rows, 1, C, as_stream(stream)));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_maxpool2_fwd_t(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream) {
+    BG_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && BG_DT_OK(dtype),
+               "bg_maxpool2_fwd_t: bad argument");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+    if (C % 4 == 0)
+        BG_DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_fwd_t_kernel<4, T>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK), 0,
+                                                as_stream(stream), (const T*)x, (T*)y, N, H, W, C));
+    else
+        BG_DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_fwd_t_kernel<1, T>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0,
+                                                as_stream(stream), (const T*)x, (T*)y, N, H, W, C));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_maxpool2_bwd_t(const void* x, const void* dy, void* dx, int dtype, int N, int H, int W, int C, void* stream) {
+    BG_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 &&
+                   BG_DT_OK(dtype), "bg_maxpool2_bwd_t: bad argument");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+    if (C % 4 == 0)
+        BG_DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_bwd_t_kernel<4, T>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK), 0,
+                                                as_stream(stream), (const T*)x, (const T*)dy, (T*)dx, N, H, W, C));
+    else
+        BG_DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_bwd_t_kernel<1, T>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0,
+                                                as_stream(stream), (const T*)x, (const T*)dy, (T*)dx, N, H, W, C));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_sum_pool_fwd_t(const void* x, int x_dtype, float* y, int N, int HW, int C, void* stream) {
+    BG_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && BG_DT_OK(x_dtype), "bg_sum_pool_fwd_t: bad argument");
+    if (C % 4 == 0)
+        BG_DISPATCH_T(x_dtype, hipLaunchKernelGGL((sum_pool_fwd_t_kernel<4, T>), dim3(ew_grid((int64_t)N * C / 4)),
+                                                  dim3(EW_BLOCK), 0, as_stream(stream), (const T*)x, y, N, HW, C));
+    else
+        BG_DISPATCH_T(x_dtype, hipLaunchKernelGGL((sum_pool_fwd_t_kernel<1, T>), dim3(ew_grid((int64_t)N * C)),
+                                                  dim3(EW_BLOCK), 0, as_stream(stream), (const T*)x, y, N, HW, C));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_sum_pool_bwd_t(const float* dy, void* dx, int x_dtype, int N, int HW, int C, void* stream) {
+    BG_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0 && BG_DT_OK(x_dtype), "bg_sum_pool_bwd_t: bad argument");
+    if (C % 4 == 0)
+        BG_DISPATCH_T(x_dtype, hipLaunchKernelGGL((sum_pool_bwd_t_kernel<4, T>), dim3(ew_grid((int64_t)N * HW * C / 4)),
+                                                  dim3(EW_BLOCK), 0, as_stream(stream), dy, (T*)dx, N, HW, C));
+    else
+        BG_DISPATCH_T(x_dtype, hipLaunchKernelGGL((sum_pool_bwd_t_kernel<1, T>), dim3(ew_grid((int64_t)N * HW * C)),
+                                                  dim3(EW_BLOCK), 0, as_stream(stream), dy, (T*)dx, N, HW, C));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_lincomb_t(const void* a, const float* sa_dev, float sa, const void* b, float sb, void* y, int dtype, int64_t n,
+                 void* stream) {
+    BG_REQUIRE(a && y && n > 0 && n % 4 == 0 && BG_DT_OK(dtype), "bg_lincomb_t: bad argument (n %% 4 == 0)");
+    BG_DISPATCH_T(dtype, hipLaunchKernelGGL((lincomb_t_kernel<T>), dim3(ew_grid(n / 4)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                            (const T*)a, sa_dev, sa, (const T*)b, sb, (T*)y, n / 4));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_dot_t(const void* a, const void* b, int dtype, float* out_accum, int64_t n, void* stream) {
+    BG_REQUIRE(a && b && out_accum && n > 0 && n % 4 == 0 && BG_DT_OK(dtype), "bg_dot_t: bad argument (n %% 4 == 0)");
+    int blocks = ew_grid(n / 4);
+    if (blocks > 512) blocks = 512;
+    BG_DISPATCH_T(dtype, hipLaunchKernelGGL((dot_t_kernel<T>), dim3(blocks), dim3(EW_BLOCK), 0, as_stream(stream),
+                                            (const T*)a, (const T*)b, out_accum, n / 4));
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -10,6 +10,7 @@
 //       dimension so small-channel layers still fill a 128-row tile and share the Bv tile.
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 namespace bg {
 
@@ -46,8 +47,6 @@ struct NNParams {
     int32_t tiles_m, tiles_n;
     int32_t kchunk;         // K-steps per channel chunk of the (chunk, tap, step) K order; 0 = all channels
     int32_t zfold;          // >0: gridDim.z folded into blockIdx.x, z fastest (phases of one M-tile share an L2)
-    const void* A16;        // bf16 copy of A (same element offsets) for the bf16-source kernels, or null
-    const void* B16;        // bf16 copy of B
 };
 
 struct TNParams {
@@ -68,5 +67,8 @@ struct TNParams {
     int32_t zfold;          // >0: gridDim.z (batch * splitk) folded into blockIdx.x, split-major per XCD
     const float* alpha;
 };
+
+// sum split-K slabs (igemm.hip): out[i] = sum_z ws[z * slab + i]
+void launch_slab_reduce(const float* ws, float* out, int64_t n, int splitk, int64_t slab, hipStream_t s);
 
 }  // namespace bg

@@ -16,15 +16,12 @@
 #include "igemm.h"
 #include "igemm_dev.h"
 #include "igemm_bf16.h"
+#include "igemm16.h"
 
-#include <atomic>
 
 namespace bg {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-// 0: fp32 MFMA (the reference's precision) ; 1: bf16 MFMA with fp32 accumulate for conv / transposed conv
-static std::atomic<int> g_gemm_compute{0};
 
 #define BKT 16  // K tile (floats)
 
@@ -594,7 +591,7 @@ __global__ __launch_bounds__(256) void slab_reduce_small_kernel(const float* __r
     }
 }
 
-static void launch_slab_reduce(const float* ws, float* out, int64_t n, int splitk, int64_t slab, hipStream_t s) {
+void launch_slab_reduce(const float* ws, float* out, int64_t n, int splitk, int64_t slab, hipStream_t s) {
     if ((n & 3) == 0 && (n >> 2) <= 16384 && splitk >= 16) {
         const int64_t n4 = n >> 2;
         hipLaunchKernelGGL(slab_reduce_small_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, s, ws, out, n4,
@@ -607,51 +604,10 @@ static void launch_slab_reduce(const float* ws, float* out, int64_t n, int split
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, out, n, splitk, slab);
 }
 
-// fp32 -> bf16 copy (RNE) of a whole operand for the bf16-source kernels (n % 8 == 0, 16-byte aligned)
-__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int64_t n8) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-        const float4 a = ld4(x + i * 8), b = ld4(x + i * 8 + 4);
-        *reinterpret_cast<bf16x8*>(y + i * 8) = cvt8(a, b);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-// Device scratch for the bf16 operand copies: grow-only, owned by the library, used in stream order (one stream).
-struct Bf16Scratch {
-    void* ptr = nullptr;
-    size_t bytes = 0;
-    void* get(size_t need) {
-        if (need <= bytes) return ptr;
-        if (ptr) {
-            (void)hipDeviceSynchronize();
-            (void)hipFree(ptr);
-        }
-        need = (need + (size_t(1) << 24)) & ~((size_t(1) << 24) - 1);
-        if (hipMalloc(&ptr, need) != hipSuccess) {
-            ptr = nullptr;
-            bytes = 0;
-            return nullptr;
-        }
-        bytes = need;
-        return ptr;
-    }
-};
-static Bf16Scratch g_a16, g_b16;
-
-static bool to_bf16(const float* x, int64_t n, Bf16Scratch& sc, const void** out, hipStream_t s) {
-    if (n <= 0 || (n & 7) || !aligned16(x)) return false;
-    void* dst = sc.get((size_t)n * 2);
-    if (!dst) return false;
-    int64_t blocks = (n / 8 + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, reinterpret_cast<__bf16*>(dst), n / 8);
-    *out = dst;
-    return true;
-}
 
 struct NNPlan {
     int bm, bn, splitk;
@@ -739,21 +695,10 @@ static void launch_nn_tile(NNParams& p, const NNPlan& pl, bool vec, bool bf16, i
         p.zfold = zdim;
         grid = dim3(p.tiles_m * p.tiles_n * zdim, 1, 1);
     }
-    if constexpr (MODE != GATHER_PLAIN && !MIRROR) {
-        if (bf16 && vec && pl.bn >= 64 && p.A16 && p.B16) {
-            if (pl.bm == 128 && pl.bn == 128)
-                hipLaunchKernelGGL((nn_kernel_bf16<2, 2, BT, MODE, false, true>), grid, dim3(256), 0, s, p);
-            else if (pl.bm == 128 && pl.bn == 64)
-                hipLaunchKernelGGL((nn_kernel_bf16<2, 1, BT, MODE, false, true>), grid, dim3(256), 0, s, p);
-            else
-                hipLaunchKernelGGL((nn_kernel_bf16<1, 1, BT, MODE, false, true>), grid, dim3(256), 0, s, p);
-            return;
-        }
-    }
     if constexpr (!BT) {
         static const int nn_btr = getenv("BG_NN_BTR") ? atoi(getenv("BG_NN_BTR")) : 1;   // weights read through ds_read_b64_tr_b16
         if (nn_btr && bf16 && vec && pl.bm == 128 && pl.bn == 128) {
-            hipLaunchKernelGGL((nn_kernel_bf16<2, 2, false, MODE, MIRROR, false, true>), grid, dim3(256), 0, s, p);
+            hipLaunchKernelGGL((nn_kernel_bf16<2, 2, false, MODE, MIRROR, true>), grid, dim3(256), 0, s, p);
             return;
         }
     }
@@ -784,8 +729,7 @@ static size_t nn_workspace_bytes(int64_t M, int N, int zdim, int niter_min, int6
 // the (MODE, BT) pairs that exist: CONV/BT0, TCONV/BT1 (+MIRROR), PLAIN/BT0, PLAIN/BT1
 static int launch_nn(NNParams& p, int mode, bool bt, bool mirror, bool vec, int zdim, int niter_min,
                      int64_t out_elems, bool out_dense, void* ws, size_t ws_bytes, hipStream_t s,
-                     bool allow_bf16 = false) {
-    const bool bf16 = allow_bf16 && g_gemm_compute.load() >= 1;
+                     bool bf16 = false) {
     NNPlan pl = plan_nn(p.M, p.N, zdim, niter_min, out_dense && ws != nullptr);
     if (pl.splitk > 1 && ws_bytes < (size_t)pl.splitk * out_elems * sizeof(float)) {
         pl = plan_nn(p.M, p.N, zdim, niter_min, false);
@@ -793,16 +737,6 @@ static int launch_nn(NNParams& p, int mode, bool bt, bool mirror, bool vec, int 
     p.splitk = pl.splitk;
     p.slabs = reinterpret_cast<float*>(ws);
     p.slab_stride = out_elems;
-    p.A16 = p.B16 = nullptr;
-    // mode 3 (experimental): whole-operand bf16 copies + the bf16-source kernel, i.e. the kernel a bf16-resident
-    // activation layout will use; with fp32 tensors in HBM the two conversion passes cost what the kernel gains
-    if (g_gemm_compute.load() >= 3 && bf16 && vec && pl.bn >= 64 && mode != GATHER_PLAIN && !mirror && p.C % 8 == 0 && p.N % 8 == 0 &&
-        p.g.ld % 8 == 0 && (mode == GATHER_TCONV ? p.ldn % 8 == 0 : p.ldk % 8 == 0)) {
-        const int64_t a_elems = (int64_t)p.g.Nb * p.g.Hs * p.g.Ws * p.g.ld;
-        const int64_t b_elems = (int64_t)p.g.k * p.g.k * p.tap_stride;
-        if (!to_bf16(p.A, a_elems, g_a16, &p.A16, s) || !to_bf16(p.B, b_elems, g_b16, &p.B16, s))
-            p.A16 = p.B16 = nullptr;
-    }
     if (mode == GATHER_CONV)
         launch_nn_tile<false, GATHER_CONV, false>(p, pl, vec, bf16, zdim, s);
     else if (mode == GATHER_TCONV && mirror)
@@ -875,7 +809,7 @@ static void launch_tn_inst(const TNParams& p, int mode, bool vec, dim3 grid, hip
 // out must be a dense [batch][Mf][Cb] block when split-K is used
 static int launch_tn(TNParams& p, int mode, bool vec, float* final_out, void* ws, size_t ws_bytes, hipStream_t s,
                      bool allow_bf16 = false) {
-    const bool bf16 = allow_bf16 && vec && g_gemm_compute.load() >= 1;
+    const bool bf16 = allow_bf16 && vec;
     TNPlan pl = plan_tn(p.Mf, p.Cb, p.batch, p.M);
     const int64_t total = (int64_t)p.batch * p.Mf * p.Cb;
     const bool dense = (p.out_ld == p.Cb) && (p.batch == 1 || p.strideC == (int64_t)p.Mf * p.Cb);
@@ -1046,151 +980,317 @@ static int tconv_min_iters(const BgConvDesc* d, int C) {
     return per_axis * per_axis * kc_of(C);
 }
 
+// ---- bf16-resident path (igemm16.hip): parameter builders -------------------------------------------
+static bool resident_fwd(const BgConvDesc* d) { return d->x_dtype == BG_BF16; }
+static bool resident_dgrad(const BgConvDesc* d) { return d->y_dtype == BG_BF16 && d->w_packed; }
+static bool resident_wgrad(const BgConvDesc* d) { return d->x_dtype == BG_BF16 && d->y_dtype == BG_BF16; }
+
+static void nn16_from(const NNParams& q, NN16Params& p) {
+    memset(&p, 0, sizeof(p));
+    p.g = q.g;
+    p.C = q.C; p.M = q.M; p.N = q.N;
+    p.tap_stride = (int64_t)q.N * q.C;
+    p.out_ld = q.out_ld;
+}
+
+// extent of the padded grid the gradient of a reflect-padded conv is computed on (a multiple of the stride)
+static int padded_extent(int out, int k, int stride) {
+    const int used = (out - 1) * stride + k;
+    return (used + stride - 1) / stride * stride;
+}
+
+static void conv16_dgrad_params(const BgConvDesc* d, bool padded, NN16Params& p) {
+    NNParams q;
+    conv_dgrad_params(d, q);
+    nn16_from(q, p);
+    if (padded) {
+        Gather& g = p.g;
+        g.Ho = padded_extent(d->Ho, d->k, d->stride);
+        g.Wo = padded_extent(d->Wo, d->k, d->stride);
+        g.Hq = g.Ho / d->stride;
+        g.Wq = g.Wo / d->stride;
+        g.pad = 0;
+        g.reflect = 0;
+        p.M = d->N * g.Hq * g.Wq;
+    }
+}
+
+static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
 }  // namespace bg
 
 using namespace bg;
 
 extern "C" {
 
-void bg_set_gemm_compute(int mode) { g_gemm_compute.store(mode >= 1 && mode <= 3 ? mode : 0); }
-int bg_get_gemm_compute(void) { return g_gemm_compute.load(); }
-
 size_t bg_conv2d_fwd_workspace_bytes(const BgConvDesc* d) {
     if (!d) return 0;
+    if (resident_fwd(d)) {
+        NNParams q;
+        conv_fwd_params(d, q);
+        NN16Params p;
+        nn16_from(q, p);
+        return nn16_workspace_bytes(p, GATHER_CONV, 1, (int64_t)p.M * d->Cout);
+    }
     return nn_workspace_bytes((int64_t)d->N * d->Ho * d->Wo, d->Cout, 1, d->k * d->k * kc_of(d->Cin),
                               (int64_t)d->N * d->Ho * d->Wo * d->Cout);
 }
 
-int bg_conv2d_fwd(const BgConvDesc* d, const float* x, const float* w, const float* bias, const float* alpha_dev,
-                  float* y, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+int bg_conv2d_fwd(const BgConvDesc* d, const void* x, const void* w, const float* bias, const float* alpha_dev,
+                  void* y, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_conv(d);
     if (rc) return rc;
     BG_REQUIRE(x && w && y, "bg_conv2d_fwd: null tensor pointer");
+    Tag tag("conv2d_fwd", d);
     NNParams p;
     conv_fwd_params(d, p);
-    p.A = x; p.B = w; p.bias = bias; p.alpha = alpha_dev; p.out = y; p.accumulate = accumulate;
+    if (resident_fwd(d)) {
+        BG_REQUIRE(d->w_packed, "bg_conv2d_fwd: bf16 input needs the packed bf16 weights (w_packed)");
+        NN16Params r;
+        nn16_from(p, r);
+        r.A = x; r.B = w; r.bias = bias; r.alpha = alpha_dev; r.out = y; r.accumulate = accumulate;
+        r.out_f32 = d->y_dtype == BG_F32;
+        ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
+        return launch_nn16(r, GATHER_CONV, 1, (int64_t)r.M * d->Cout, ws, ws_bytes, as_stream(stream));
+    }
+    BG_REQUIRE(d->y_dtype == BG_F32 && !d->w_packed, "bg_conv2d_fwd: fp32 input needs fp32 weights and output");
+    p.A = (const float*)x; p.B = (const float*)w; p.bias = bias; p.alpha = alpha_dev; p.out = (float*)y;
+    p.accumulate = accumulate;
     const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
-    Tag tag("conv2d_fwd", d);
     ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
     return launch_nn(p, GATHER_CONV, false, false, vec, 1, d->k * d->k * kc_of(d->Cin),
-                     (int64_t)p.M * d->Cout, true, ws, ws_bytes, as_stream(stream), true);
+                     (int64_t)p.M * d->Cout, true, ws, ws_bytes, as_stream(stream), d->compute == BG_COMPUTE_BF16);
 }
 
 size_t bg_conv2d_dgrad_workspace_bytes(const BgConvDesc* d) {
     if (!d) return 0;
-    UnevenPhases uneven(d);
     const int z = d->stride * d->stride;
+    if (resident_dgrad(d)) {
+        const bool padded = d->pad_mode == BG_PAD_REFLECT && d->pad_lo > 0;
+        NN16Params p;
+        conv16_dgrad_params(d, padded, p);
+        const int64_t out_elems = (int64_t)d->N * p.g.Ho * p.g.Wo * d->Cin;
+        size_t b = nn16_workspace_bytes(p, GATHER_TCONV, z, out_elems);
+        if (padded) b = align256(b) + align256((size_t)out_elems * (d->x_dtype == BG_F32 ? 4 : 2));
+        return b;
+    }
+    UnevenPhases uneven(d);
     return nn_workspace_bytes((int64_t)d->N * (d->H / d->stride) * (d->W / d->stride), d->Cin, z,
                               tconv_min_iters(d, d->Cout), (int64_t)d->N * d->H * d->W * d->Cin);
 }
 
-int bg_conv2d_dgrad(const BgConvDesc* d, const float* dy, const float* w, const float* alpha_dev, float* dx,
+int bg_conv2d_dgrad(const BgConvDesc* d, const void* dy, const void* w, const float* alpha_dev, void* dx,
                     int accumulate, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_conv(d);
     if (rc) return rc;
     BG_REQUIRE(dy && w && dx, "bg_conv2d_dgrad: null tensor pointer");
     BG_REQUIRE(d->H % d->stride == 0 && d->W % d->stride == 0, "conv dgrad: H,W must be multiples of stride");
+    Tag tag("conv2d_dgrad", d);
+    if (resident_dgrad(d)) {
+        const bool padded = d->pad_mode == BG_PAD_REFLECT && d->pad_lo > 0;
+        NN16Params r;
+        conv16_dgrad_params(d, padded, r);
+        r.A = dy; r.B = w; r.alpha = alpha_dev;
+        r.out_f32 = d->x_dtype == BG_F32;
+        const int64_t out_elems = (int64_t)d->N * r.g.Ho * r.g.Wo * d->Cin;
+        ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
+        if (!padded) {
+            r.out = dx; r.accumulate = accumulate;
+            return launch_nn16(r, GATHER_TCONV, d->stride * d->stride, out_elems, ws, ws_bytes, as_stream(stream));
+        }
+        // gradient on the reflect-padded grid, then every padded position is added to the pixel it mirrors
+        const size_t pbytes = align256((size_t)out_elems * (r.out_f32 ? 4 : 2));
+        BG_REQUIRE(ws && ws_bytes >= pbytes, "bg_conv2d_dgrad: workspace too small for the padded gradient");
+        r.out = ws; r.accumulate = 0;
+        char* slabs = reinterpret_cast<char*>(ws) + pbytes;
+        rc = launch_nn16(r, GATHER_TCONV, d->stride * d->stride, out_elems, ws_bytes > pbytes ? slabs : nullptr,
+                         ws_bytes - pbytes, as_stream(stream));
+        if (rc) return rc;
+        return launch_reflect_fold(ws, dx, r.out_f32, d->N, d->H, d->W, d->Cin, r.g.Ho, r.g.Wo, d->pad_lo, accumulate,
+                                   as_stream(stream));
+    }
+    BG_REQUIRE(d->x_dtype == BG_F32 && d->y_dtype == BG_F32 && !d->w_packed, "bg_conv2d_dgrad: unsupported dtype mix");
     UnevenPhases uneven(d);
     NNParams p;
     conv_dgrad_params(d, p);
-    p.A = dy; p.B = w; p.alpha = alpha_dev; p.out = dx; p.accumulate = accumulate;
+    p.A = (const float*)dy; p.B = (const float*)w; p.alpha = alpha_dev; p.out = (float*)dx; p.accumulate = accumulate;
     const bool vec = (d->Cout % 4 == 0) && aligned16(dy) && aligned16(w);
-    Tag tag("conv2d_dgrad", d);
     ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
     return launch_nn(p, GATHER_TCONV, true, p.g.reflect != 0, vec, d->stride * d->stride, tconv_min_iters(d, d->Cout),
-                     (int64_t)d->N * d->H * d->W * d->Cin, true, ws, ws_bytes, as_stream(stream), true);
+                     (int64_t)d->N * d->H * d->W * d->Cin, true, ws, ws_bytes, as_stream(stream),
+                     d->compute == BG_COMPUTE_BF16);
+}
+
+static void conv16_wgrad_params(const BgConvDesc* d, TN16Params& p) {
+    memset(&p, 0, sizeof(p));
+    Gather& g = p.g;
+    g.Nb = d->N; g.Hs = d->H; g.Ws = d->W; g.Ho = d->Ho; g.Wo = d->Wo; g.Hq = d->Ho; g.Wq = d->Wo; g.pstep = 1;
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.reflect = d->pad_mode == BG_PAD_REFLECT; g.ld = d->Cin;
+    p.Ca = d->Cin; p.Cb = d->Cout; p.Mf = d->k * d->k * d->Cin; p.b_ld = d->Cout; p.M = d->N * d->Ho * d->Wo;
+    p.out_ld = d->Cout;
 }
 
 size_t bg_conv2d_wgrad_workspace_bytes(const BgConvDesc* d) {
     if (!d) return 0;
+    if (resident_wgrad(d)) {
+        TN16Params p;
+        conv16_wgrad_params(d, p);
+        return tn16_workspace_bytes(p);
+    }
     return tn_workspace_bytes(d->k * d->k * d->Cin, d->Cout, 1, d->N * d->Ho * d->Wo);
 }
 
-int bg_conv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
+int bg_conv2d_wgrad(const BgConvDesc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes,
                     void* stream) {
     int rc = check_conv(d);
     if (rc) return rc;
     BG_REQUIRE(x && dy && dw, "bg_conv2d_wgrad: null tensor pointer");
+    Tag tag("conv2d_wgrad", d);
+    if (resident_wgrad(d)) {
+        TN16Params r;
+        conv16_wgrad_params(d, r);
+        r.A = x; r.Bv = dy;
+        ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
+        return launch_tn16(r, GATHER_CONV, dw, ws, ws_bytes, as_stream(stream));
+    }
+    BG_REQUIRE(d->x_dtype == BG_F32 && d->y_dtype == BG_F32, "bg_conv2d_wgrad: x and dy must both be fp32 or both bf16");
     TNParams p;
     memset(&p, 0, sizeof(p));
-    p.A = x; p.Bv = dy;
+    p.A = (const float*)x; p.Bv = (const float*)dy;
     Gather& g = p.g;
     g.Nb = d->N; g.Hs = d->H; g.Ws = d->W; g.Ho = d->Ho; g.Wo = d->Wo; g.Hq = d->Ho; g.Wq = d->Wo; g.pstep = 1;
     g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.reflect = d->pad_mode == BG_PAD_REFLECT; g.ld = d->Cin;
     p.Ca = d->Cin; p.Cb = d->Cout; p.Mf = d->k * d->k * d->Cin; p.b_ld = d->Cout; p.M = d->N * d->Ho * d->Wo;
     p.out_ld = d->Cout; p.batch = 1;
     const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(dy);
-    Tag tag("conv2d_wgrad", d);
     ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
-    return launch_tn(p, GATHER_CONV, vec, dw, ws, ws_bytes, as_stream(stream), true);
+    return launch_tn(p, GATHER_CONV, vec, dw, ws, ws_bytes, as_stream(stream), d->compute == BG_COMPUTE_BF16);
 }
 
 size_t bg_deconv2d_fwd_workspace_bytes(const BgConvDesc* d) {
     if (!d) return 0;
     const int z = d->stride * d->stride;
+    if (resident_fwd(d)) {
+        NNParams q;
+        deconv_fwd_params(d, q);
+        NN16Params p;
+        nn16_from(q, p);
+        return nn16_workspace_bytes(p, GATHER_TCONV, z, (int64_t)d->N * d->Ho * d->Wo * d->Cout);
+    }
     return nn_workspace_bytes((int64_t)d->N * d->H * d->W, d->Cout, z, tconv_min_iters(d, d->Cin),
                               (int64_t)d->N * d->Ho * d->Wo * d->Cout);
 }
 
-int bg_deconv2d_fwd(const BgConvDesc* d, const float* x, const float* w, const float* bias, const float* alpha_dev,
-                    float* y, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+int bg_deconv2d_fwd(const BgConvDesc* d, const void* x, const void* w, const float* bias, const float* alpha_dev,
+                    void* y, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_deconv(d);
     if (rc) return rc;
     BG_REQUIRE(x && w && y, "bg_deconv2d_fwd: null tensor pointer");
+    Tag tag("deconv2d_fwd", d);
     NNParams p;
     deconv_fwd_params(d, p);
-    p.A = x; p.B = w; p.bias = bias; p.alpha = alpha_dev; p.out = y; p.accumulate = accumulate;
+    if (resident_fwd(d)) {
+        BG_REQUIRE(d->w_packed, "bg_deconv2d_fwd: bf16 input needs the packed bf16 weights (w_packed)");
+        NN16Params r;
+        nn16_from(p, r);
+        r.A = x; r.B = w; r.bias = bias; r.alpha = alpha_dev; r.out = y; r.accumulate = accumulate;
+        r.out_f32 = d->y_dtype == BG_F32;
+        ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
+        return launch_nn16(r, GATHER_TCONV, d->stride * d->stride, (int64_t)d->N * d->Ho * d->Wo * d->Cout, ws, ws_bytes,
+                           as_stream(stream));
+    }
+    BG_REQUIRE(d->y_dtype == BG_F32 && !d->w_packed, "bg_deconv2d_fwd: fp32 input needs fp32 weights and output");
+    p.A = (const float*)x; p.B = (const float*)w; p.bias = bias; p.alpha = alpha_dev; p.out = (float*)y;
+    p.accumulate = accumulate;
     const bool vec = (d->Cin % 4 == 0) && aligned16(x) && aligned16(w);
-    Tag tag("deconv2d_fwd", d);
     ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
     return launch_nn(p, GATHER_TCONV, true, false, vec, d->stride * d->stride, tconv_min_iters(d, d->Cin),
-                     (int64_t)d->N * d->Ho * d->Wo * d->Cout, true, ws, ws_bytes, as_stream(stream), true);
+                     (int64_t)d->N * d->Ho * d->Wo * d->Cout, true, ws, ws_bytes, as_stream(stream),
+                     d->compute == BG_COMPUTE_BF16);
 }
 
 size_t bg_deconv2d_dgrad_workspace_bytes(const BgConvDesc* d) {
     if (!d) return 0;
+    if (resident_dgrad(d)) {
+        NNParams q;
+        deconv_dgrad_params(d, q);
+        NN16Params p;
+        nn16_from(q, p);
+        return nn16_workspace_bytes(p, GATHER_CONV, 1, (int64_t)d->N * d->H * d->W * d->Cin);
+    }
     return nn_workspace_bytes((int64_t)d->N * d->H * d->W, d->Cin, 1, d->k * d->k * kc_of(d->Cout),
                               (int64_t)d->N * d->H * d->W * d->Cin);
 }
 
-int bg_deconv2d_dgrad(const BgConvDesc* d, const float* dy, const float* w, const float* alpha_dev, float* dx,
+int bg_deconv2d_dgrad(const BgConvDesc* d, const void* dy, const void* w, const float* alpha_dev, void* dx,
                       int accumulate, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_deconv(d);
     if (rc) return rc;
     BG_REQUIRE(dy && w && dx, "bg_deconv2d_dgrad: null tensor pointer");
+    Tag tag("deconv2d_dgrad", d);
     NNParams p;
     deconv_dgrad_params(d, p);
-    p.A = dy; p.B = w; p.alpha = alpha_dev; p.out = dx; p.accumulate = accumulate;
+    if (resident_dgrad(d)) {
+        NN16Params r;
+        nn16_from(p, r);
+        r.A = dy; r.B = w; r.alpha = alpha_dev; r.out = dx; r.accumulate = accumulate;
+        r.out_f32 = d->x_dtype == BG_F32;
+        ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
+        return launch_nn16(r, GATHER_CONV, 1, (int64_t)r.M * d->Cin, ws, ws_bytes, as_stream(stream));
+    }
+    BG_REQUIRE(d->x_dtype == BG_F32 && d->y_dtype == BG_F32 && !d->w_packed, "bg_deconv2d_dgrad: unsupported dtype mix");
+    p.A = (const float*)dy; p.B = (const float*)w; p.alpha = alpha_dev; p.out = (float*)dx; p.accumulate = accumulate;
     const bool vec = (d->Cout % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy) && aligned16(w);
-    Tag tag("deconv2d_dgrad", d);
     ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
     return launch_nn(p, GATHER_CONV, false, false, vec, 1, d->k * d->k * kc_of(d->Cout),
-                     (int64_t)p.M * d->Cin, true, ws, ws_bytes, as_stream(stream), true);
+                     (int64_t)p.M * d->Cin, true, ws, ws_bytes, as_stream(stream), d->compute == BG_COMPUTE_BF16);
+}
+
+static void deconv16_wgrad_params(const BgConvDesc* d, TN16Params& p) {
+    memset(&p, 0, sizeof(p));
+    Gather& g = p.g;
+    g.Nb = d->N; g.Hs = d->Ho; g.Ws = d->Wo; g.Ho = d->H; g.Wo = d->W; g.Hq = d->H; g.Wq = d->W; g.pstep = 1;
+    g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.reflect = 0; g.ld = d->Cout;
+    p.Ca = d->Cout; p.Cb = d->Cin; p.Mf = d->k * d->k * d->Cout; p.b_ld = d->Cin; p.M = d->N * d->H * d->W;
+    p.out_ld = d->Cin;
 }
 
 size_t bg_deconv2d_wgrad_workspace_bytes(const BgConvDesc* d) {
     if (!d) return 0;
+    if (resident_wgrad(d)) {
+        TN16Params p;
+        deconv16_wgrad_params(d, p);
+        return tn16_workspace_bytes(p);
+    }
     return tn_workspace_bytes(d->k * d->k * d->Cout, d->Cin, 1, d->N * d->H * d->W);
 }
 
-int bg_deconv2d_wgrad(const BgConvDesc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
+int bg_deconv2d_wgrad(const BgConvDesc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes,
                       void* stream) {
     int rc = check_deconv(d);
     if (rc) return rc;
     BG_REQUIRE(x && dy && dw, "bg_deconv2d_wgrad: null tensor pointer");
+    Tag tag("deconv2d_wgrad", d);
     // dw[kh,kw,co,ci] = sum_{b,hi,wi} dy[b, hi*s+kh-pad, wi*s+kw-pad, co] * x[b,hi,wi,ci]
+    if (resident_wgrad(d)) {
+        TN16Params r;
+        deconv16_wgrad_params(d, r);
+        r.A = dy; r.Bv = x;
+        ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
+        return launch_tn16(r, GATHER_CONV, dw, ws, ws_bytes, as_stream(stream));
+    }
+    BG_REQUIRE(d->x_dtype == BG_F32 && d->y_dtype == BG_F32, "bg_deconv2d_wgrad: x and dy must both be fp32 or both bf16");
     TNParams p;
     memset(&p, 0, sizeof(p));
-    p.A = dy; p.Bv = x;
+    p.A = (const float*)dy; p.Bv = (const float*)x;
     Gather& g = p.g;
     g.Nb = d->N; g.Hs = d->Ho; g.Ws = d->Wo; g.Ho = d->H; g.Wo = d->W; g.Hq = d->H; g.Wq = d->W; g.pstep = 1;
     g.k = d->k; g.stride = d->stride; g.pad = d->pad_lo; g.reflect = 0; g.ld = d->Cout;
     p.Ca = d->Cout; p.Cb = d->Cin; p.Mf = d->k * d->k * d->Cout; p.b_ld = d->Cin; p.M = d->N * d->H * d->W;
     p.out_ld = d->Cin; p.batch = 1;
     const bool vec = (d->Cout % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy) && aligned16(x);
-    Tag tag("deconv2d_wgrad", d);
     ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
-    return launch_tn(p, GATHER_CONV, vec, dw, ws, ws_bytes, as_stream(stream), true);
+    return launch_tn(p, GATHER_CONV, vec, dw, ws, ws_bytes, as_stream(stream), d->compute == BG_COMPUTE_BF16);
 }
 
 size_t bg_gemm_workspace_bytes(const BgGemmDesc* d) {
@@ -1199,12 +1299,6 @@ size_t bg_gemm_workspace_bytes(const BgGemmDesc* d) {
     if (d->transA) return tn_workspace_bytes(d->M, d->N, batch, d->K);
     if (d->ldc != d->N || batch != 1) return 0;
     return nn_workspace_bytes(d->M, d->N, 1, kc_of(d->K), (int64_t)d->M * d->N);
-}
-
-// compute mode 2: the large plain GEMMs too (regulariser Grams and their gradients: batch-independent
-// work that is 20 % of the step at ch = 96, batch 32); small / skinny ones (dense layers, cond-BN FCs) stay fp32
-static bool gemm_wants_bf16(const BgGemmDesc* d) {
-    return g_gemm_compute.load() >= 2 && d->M >= 128 && d->N >= 128 && d->K >= 128;
 }
 
 int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bias, const float* alpha_dev,
@@ -1231,7 +1325,7 @@ int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bi
         ProfScope prof(as_stream(stream), flops, tag.s);
         const bool dense = d->ldc == d->N && d->batch == 1;
         return launch_nn(p, GATHER_PLAIN, d->transB != 0, false, vec, d->batch, kc_of(d->K), (int64_t)d->M * d->N,
-                         dense, dense ? ws : nullptr, ws_bytes, as_stream(stream), gemm_wants_bf16(d));
+                         dense, dense ? ws : nullptr, ws_bytes, as_stream(stream), d->compute == BG_COMPUTE_BF16);
     }
     BG_REQUIRE(!d->transB, "bg_gemm: transA && transB unsupported");
     BG_REQUIRE(bias == nullptr && !accumulate, "bg_gemm: transA path has no bias / accumulate");
@@ -1247,7 +1341,7 @@ int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bi
     const bool vec = (d->M % 4 == 0) && (d->lda % 4 == 0) && (d->strideA % 4 == 0) && aligned16(A) &&
                      (d->N % 4 == 0) && (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
     ProfScope prof(as_stream(stream), flops, tag.s);
-    return launch_tn(p, GATHER_PLAIN, vec, C, ws, ws_bytes, as_stream(stream), gemm_wants_bf16(d));
+    return launch_tn(p, GATHER_PLAIN, vec, C, ws, ws_bytes, as_stream(stream), d->compute == BG_COMPUTE_BF16);
 }
 
 }  // extern "C"

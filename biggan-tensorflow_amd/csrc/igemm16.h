@@ -1,0 +1,60 @@
+// igemm16.h - host interface of the bf16-RESIDENT implicit-GEMM kernels (igemm16.hip).
+//
+// Tensors of this path are bf16 in HBM (activations NHWC, weights as K-contiguous packed copies written by the
+// spectral-norm kernels, BgConvDesc::w_packed); tiles travel global -> LDS with global_load_lds_dwordx4 (no VGPR
+// staging, no conversion in the loop), accumulate in fp32 on v_mfma_f32_16x16x32_bf16 and leave as bf16 or fp32.
+#pragma once
+#include <stdint.h>
+
+#include "igemm.h"
+
+namespace bg {
+
+struct NN16Params {
+    const void* A;          // bf16 source tensor of the gather
+    const void* B;          // bf16 weights [tap][N][C] (C contiguous)
+    const float* bias;      // [N] fp32 or null
+    const float* alpha;     // device scalar or null
+    void* out;              // bf16 or fp32, rows of out_ld elements
+    float* slabs;           // split-K partial sums in output coordinates (splitk > 1)
+    Gather g;
+    int32_t C;              // channels per tap, multiple of 8 (K = taps * C)
+    int32_t M, N;
+    int64_t tap_stride;     // weight elements between taps (= N * C)
+    int32_t out_ld;
+    int32_t out_f32;        // 1: out is fp32
+    int32_t accumulate;     // out += result (same dtype as out)
+    int32_t splitk;
+    int64_t slab_stride;
+    int32_t tiles_m, tiles_n;
+    int32_t zfold;
+};
+
+struct TN16Params {
+    const void* A;          // bf16, gathered (CONV mode) pixel rows of Ca channels
+    const void* Bv;         // bf16, pixel rows of Cb channels
+    float* out;             // fp32 [Mf][Cb] or slabs [split][Mf][Cb]
+    Gather g;
+    int32_t Ca, Cb;
+    int32_t Mf;             // taps * Ca
+    int32_t b_ld;
+    int32_t M;              // reduction length (pixels)
+    int32_t splitk, rows_per_split;
+    int64_t slab_stride;
+    int32_t out_ld;
+    int32_t tiles_m, tiles_n;
+    int32_t pow2;           // Wq and Hq are powers of two: shifts instead of divisions in the pixel walk
+    int32_t wq_shift, hq_shift;
+};
+
+// conv-family entry points of the bf16-resident path (called from igemm.hip's extern "C" functions)
+size_t nn16_workspace_bytes(const NN16Params& p, int mode, int zdim, int64_t out_elems);
+int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, size_t ws_bytes, hipStream_t s);
+size_t tn16_workspace_bytes(const TN16Params& p);
+int launch_tn16(TN16Params& p, int mode, float* final_out, void* ws, size_t ws_bytes, hipStream_t s);
+// dx[b,h,w,:] (+)= sum of the padded-grid gradient dxp[b,i,j,:] over the padded positions (i,j) that tf.pad(REFLECT)
+// filled from pixel (h,w) (the transpose of ops.py:82's padding); f32: both tensors fp32, else both bf16
+int launch_reflect_fold(const void* dxp, void* dx, int f32, int N, int H, int W, int C, int Hp, int Wp, int pad_lo,
+                        int accumulate, hipStream_t s);
+
+}  // namespace bg

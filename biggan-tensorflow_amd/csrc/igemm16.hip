@@ -1,0 +1,755 @@
+// igemm16.hip - bf16-RESIDENT implicit-GEMM kernels for conv / transposed conv and their gradients (gfx950).
+//
+// Reference call sites replaced: tf.pad + tf.nn.conv2d (ops.py:82,94-98), tf.nn.conv2d_transpose (ops.py:127-132)
+// and the gradients TensorFlow derives for them, in the bf16 configurations of BASELINE.json (configs 3-5).
+//
+// Why a second family next to igemm.hip / igemm_bf16.h: those kernels read fp32 tensors and round to bf16 while
+// staging through VGPRs, which left the bf16 MFMA pipe 80-90 % idle.  Here every operand is
+// ALREADY bf16 in HBM, so a tile goes global -> LDS with global_load_lds_dwordx4 (16 bytes per lane, no VGPRs, no
+// VALU conversion), the gather of the implicit GEMM is just the per-lane SOURCE address of that instruction, and the
+// K loop is {issue next tile's LDS-DMA ; ds_read_b128 fragments ; MFMA ; barrier}.
+//
+//   nn16_kernel  out[m, n] = sum_tap sum_c A(pixel(m), tap)[c] * B[tap][n][c]        (forward, input gradients)
+//       block tile 128 x (32*TN) x 64, 4 waves (2 x 2), v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+//       LDS image: rows of 64 bf16 (128 B); 16-byte chunk c of row r is stored at chunk position c ^ ((r >> 1) & 7):
+//       LDS-DMA writes are lane-linear, so the swizzle is applied to the SOURCE chunk each lane fetches, and the
+//       ds_read_b128 operand reads (lane -> row lane & 15, chunk lane >> 4) are bank-conflict free.
+//       K is flattened over (tap, channel chunk): a 64-wide K step may straddle taps (C = 96), every lane keeps its
+//       own (tap, channel) cursor.  Out-of-image taps, rows >= M, columns >= N and the K tail fetch a zero page.
+//       The epilogue transposes the accumulators through LDS and stores whole 16-byte row segments
+//       (bias, alpha, residual accumulate, bf16 or fp32 output).
+//   tn16_kernel  out[(tap, ca)][cb] = sum_pixels A(pixel, tap)[ca] * Bv(pixel)[cb]   (weight gradients)
+//       both tiles stay PIXEL-major in LDS ([64 pixels][128 channels] bf16, chunk-swizzled) and the MFMA operands
+//       are read transposed with ds_read_b64_tr_b16; fp32 split-K slabs over pixel ranges.
+#include <stdlib.h>
+
+#include "common.h"
+#include "igemm.h"
+#include "igemm16.h"
+#include "igemm_dev.h"
+
+namespace bg {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+typedef short s16x8v __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+typedef __attribute__((address_space(3))) s16x4v lds_s16x4v;
+
+// the source of every out-of-range 16-byte chunk (zero-initialised device memory of the code object)
+__device__ uint4 g_zero_page[4];
+
+__device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
+    // LDS destination = wave-uniform base + lane * 16 ; the global source address is per lane
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// ------------------------------------------------------------------------------------------
+// NN kernel
+// ------------------------------------------------------------------------------------------
+constexpr int NN16_BM = 128;      // block tile rows; the K step is 64 bf16 = one 128-byte LDS row
+constexpr int nn16_lds_bytes(int TN) {
+    const int stage = (NN16_BM + 32 * TN) * 128;
+    const int epi = NN16_BM * (32 * TN + 4) * 4;
+    return 2 * stage > epi ? 2 * stage : epi;
+}
+
+template <int TN, int MODE>
+__global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
+    constexpr int BM = NN16_BM, BN = 32 * TN;
+    constexpr int JA = BM / 32, JB = BN / 32;      // LDS-DMA instructions per wave and K step
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const Gather& g = p.g;
+
+    int tile, bz = blockIdx.z;
+    if (p.zfold > 0) {
+        const int lin = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.zfold);
+        bz = lin % p.zfold;
+        tile = lin / p.zfold;
+    } else {
+        tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    }
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int zs = bz % p.splitk, zo = bz / p.splitk;
+
+    int ph = 0, pw = 0;
+    if (MODE == GATHER_TCONV) {
+        ph = g.pstep - 1 - zo / g.pstep;           // heaviest stride phase first
+        pw = g.pstep - 1 - zo % g.pstep;
+    }
+    int kh0 = 0, kw0 = 0, kstep = 1, nkh = g.k, nkw = g.k;
+    if (MODE == GATHER_TCONV && g.pstep > 1) {
+        kstep = g.stride;
+        kh0 = (ph + g.pad) % g.stride;
+        kw0 = (pw + g.pad) % g.stride;
+        nkh = (g.k - kh0 + g.stride - 1) / g.stride;
+        nkw = (g.k - kw0 + g.stride - 1) / g.stride;
+    }
+    const int C8 = p.C >> 3;
+    const int ntap = nkh * nkw;
+    const int nsteps_all = (ntap * C8 + 7) >> 3;
+    const int sps = (nsteps_all + p.splitk - 1) / p.splitk;
+    const int it0 = zs * sps;
+    const int nsteps = max(0, min(nsteps_all, it0 + sps) - it0);
+
+    // ---- staging role of this lane: 16-byte chunk `cch` of the K step, rows 32 j + rsub of both tiles ----
+    const int cch = (lane & 7) ^ ((((w & 1) << 2) | (lane >> 4)) & 7);
+    const int rsub = 8 * w + (lane >> 3);
+    RowPos rows[JA];
+#pragma unroll
+    for (int j = 0; j < JA; ++j) rows[j] = decompose_row<MODE>(g, m0 + 32 * j + rsub, p.M, ph, pw);
+    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
+    const __bf16* Bb = reinterpret_cast<const __bf16*>(p.B);
+    const void* zero = reinterpret_cast<const void*>(g_zero_page);
+
+    int tidx, c8;
+    {
+        const int kk = it0 * 8 + cch;
+        tidx = kk / C8;
+        c8 = kk - tidx * C8;
+    }
+    int64_t aoff[JA];
+    const __bf16* wtap = Bb;
+    auto set_tap = [&]() {
+        if (tidx < ntap) {
+            const int ih = tidx / nkw, iw = tidx - ih * nkw;
+            const int kh = kh0 + ih * kstep, kw = kw0 + iw * kstep;
+#pragma unroll
+            for (int j = 0; j < JA; ++j) {
+                int64_t off[1];
+                tap_sources<MODE, false>(g, rows[j], kh, kw, off);
+                aoff[j] = off[0];
+            }
+            wtap = Bb + (int64_t)(kh * g.k + kw) * p.tap_stride;
+        } else {
+#pragma unroll
+            for (int j = 0; j < JA; ++j) aoff[j] = -1;
+        }
+    };
+    set_tap();
+
+    auto stage = [&](int buf) {
+        unsigned char* sa = smem + buf * STAGE + (8 * w) * 128;
+        unsigned char* sb = sa + A_BYTES;
+        const bool kvalid = tidx < ntap;
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+            const void* src = aoff[j] >= 0 ? static_cast<const void*>(Ab + aoff[j] + c8 * 8) : zero;
+            glds16(src, sa + j * 32 * 128);
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const int n = n0 + 32 * j + rsub;
+            const void* src = (kvalid && n < p.N) ? static_cast<const void*>(wtap + (int64_t)n * p.C + c8 * 8) : zero;
+            glds16(src, sb + j * 32 * 128);
+        }
+        c8 += 8;
+        if (c8 >= C8) {
+            do {
+                c8 -= C8;
+                ++tidx;
+            } while (c8 >= C8);
+            set_tap();
+        }
+    };
+
+    f32x4_t acc[4][TN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // operand reads: lane -> row (lane & 15) of a 16-row fragment, chunk 4 s + (lane >> 4), swizzled by (row >> 1) & 7
+    const int fsw = (lane & 15) >> 1;
+    const int a_row = (wm * 64 + (lane & 15)) * 128;
+    const int b_row = A_BYTES + (wn * 16 * TN + (lane & 15)) * 128;
+    int koff[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) koff[s2] = 16 * ((4 * s2 + (lane >> 4)) ^ fsw);
+
+    if (nsteps > 0) stage(0);
+    __syncthreads();
+
+    for (int it = 0; it < nsteps; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nsteps) stage(cur ^ 1);
+        const unsigned char* sbuf = smem + cur * STAGE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8_t a[4], b[TN];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const bf16x8_t*>(sbuf + a_row + i * 16 * 128 + koff[s2]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const bf16x8_t*>(sbuf + b_row + j * 16 * 128 + koff[s2]);
+            // weights as the MFMA's first operand: D rows = output channels (4 per lane), D columns = pixels
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS [128][BN + 4] fp32 -> whole 16-byte row segments ----
+    constexpr int ELD = BN + 4;
+    float* est = reinterpret_cast<float*>(smem);
+    const bool partial = p.splitk > 1;
+    const float alpha = (!partial && p.alpha) ? *p.alpha : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wm * 64 + 16 * i + (lane & 15);
+            const int col = wn * 16 * TN + 16 * j + 4 * (lane >> 4);
+            f32x4_t v = acc[i][j];
+            v[0] *= alpha; v[1] *= alpha; v[2] *= alpha; v[3] *= alpha;
+            *reinterpret_cast<f32x4_t*>(est + row * ELD + col) = v;
+        }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                     // 8-column chunks per row
+    float* slab = partial ? p.slabs + (int64_t)zs * p.slab_stride : nullptr;
+#pragma unroll
+    for (int q = 0; q < BM * CPR / 256; ++q) {
+        const int idx = t + 256 * q;
+        const int row = idx / CPR, cc = idx - row * CPR;
+        const int m = m0 + row, col = n0 + cc * 8;
+        if (m >= p.M || col >= p.N) continue;
+        int64_t ooff;
+        if (MODE == GATHER_TCONV) {
+            const RowPos rp = decompose_row<MODE>(g, m, p.M, ph, pw);
+            if (rp.ho >= g.Ho || rp.wo >= g.Wo) continue;
+            ooff = (((int64_t)rp.b * g.Ho + rp.ho) * g.Wo + rp.wo) * p.out_ld + col;
+        } else {
+            ooff = (int64_t)m * p.out_ld + col;
+        }
+        f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(est + row * ELD + cc * 8);
+        f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(est + row * ELD + cc * 8 + 4);
+        if (partial) {
+            *reinterpret_cast<f32x4_t*>(slab + ooff) = v0;
+            *reinterpret_cast<f32x4_t*>(slab + ooff + 4) = v1;
+            continue;
+        }
+        if (p.bias) {
+            const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.bias + col);
+            const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(p.bias + col + 4);
+            v0 += b0;
+            v1 += b1;
+        }
+        if (p.out_f32) {
+            float* o = reinterpret_cast<float*>(p.out) + ooff;
+            if (p.accumulate) {
+                v0 += *reinterpret_cast<const f32x4_t*>(o);
+                v1 += *reinterpret_cast<const f32x4_t*>(o + 4);
+            }
+            *reinterpret_cast<f32x4_t*>(o) = v0;
+            *reinterpret_cast<f32x4_t*>(o + 4) = v1;
+        } else {
+            __bf16* o = reinterpret_cast<__bf16*>(p.out) + ooff;
+            if (p.accumulate) {
+                const uint4 r = *reinterpret_cast<const uint4*>(o);
+                v0[0] += bf16_lo(r.x); v0[1] += bf16_hi(r.x); v0[2] += bf16_lo(r.y); v0[3] += bf16_hi(r.y);
+                v1[0] += bf16_lo(r.z); v1[1] += bf16_hi(r.z); v1[2] += bf16_lo(r.w); v1[3] += bf16_hi(r.w);
+            }
+            uint4 r;
+            r.x = pack_bf16x2(v0[0], v0[1]);
+            r.y = pack_bf16x2(v0[2], v0[3]);
+            r.z = pack_bf16x2(v1[0], v1[1]);
+            r.w = pack_bf16x2(v1[2], v1[3]);
+            *reinterpret_cast<uint4*>(o) = r;
+        }
+    }
+}
+
+// out = alpha * sum_z slabs[z] (+ bias) (+ out), 8 elements per thread; n8 = elements / 8, N % 8 == 0
+__global__ __launch_bounds__(256) void nn16_slab_reduce_kernel(const float* __restrict__ slabs, void* __restrict__ out,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ alpha_dev, int64_t n8, int N,
+                                                               int splitk, int64_t slab_stride, int accumulate,
+                                                               int out_f32) {
+    const float alpha = alpha_dev ? *alpha_dev : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        for (int z = 0; z < splitk; ++z) {
+            const float* sp = slabs + (int64_t)z * slab_stride + i * 8;
+            s0 += *reinterpret_cast<const f32x4_t*>(sp);
+            s1 += *reinterpret_cast<const f32x4_t*>(sp + 4);
+        }
+        s0 *= alpha;
+        s1 *= alpha;
+        if (bias) {
+            const int col = (int)((i * 8) % N);
+            s0 += *reinterpret_cast<const f32x4_t*>(bias + col);
+            s1 += *reinterpret_cast<const f32x4_t*>(bias + col + 4);
+        }
+        if (out_f32) {
+            float* o = reinterpret_cast<float*>(out) + i * 8;
+            if (accumulate) {
+                s0 += *reinterpret_cast<const f32x4_t*>(o);
+                s1 += *reinterpret_cast<const f32x4_t*>(o + 4);
+            }
+            *reinterpret_cast<f32x4_t*>(o) = s0;
+            *reinterpret_cast<f32x4_t*>(o + 4) = s1;
+        } else {
+            __bf16* o = reinterpret_cast<__bf16*>(out) + i * 8;
+            if (accumulate) {
+                const uint4 r = *reinterpret_cast<const uint4*>(o);
+                s0[0] += bf16_lo(r.x); s0[1] += bf16_hi(r.x); s0[2] += bf16_lo(r.y); s0[3] += bf16_hi(r.y);
+                s1[0] += bf16_lo(r.z); s1[1] += bf16_hi(r.z); s1[2] += bf16_lo(r.w); s1[3] += bf16_hi(r.w);
+            }
+            uint4 r;
+            r.x = pack_bf16x2(s0[0], s0[1]);
+            r.y = pack_bf16x2(s0[2], s0[3]);
+            r.z = pack_bf16x2(s1[0], s1[1]);
+            r.w = pack_bf16x2(s1[2], s1[3]);
+            *reinterpret_cast<uint4*>(o) = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN kernel (weight gradients): K = pixels, both operands pixel-major in LDS, transposed operand reads
+// ------------------------------------------------------------------------------------------
+constexpr int TN16_BK = 64;
+constexpr int TN16_TILE = TN16_BK * 256;            // bytes of one [64 pixels][128 channels] bf16 image
+
+__device__ __forceinline__ s16x4v lds_tr16(uint32_t lds_byte_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4v*>(lds_byte_addr));
+}
+__device__ __forceinline__ int tr16_swz(int row, int chunk) {
+    return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void tn16_kernel(const TN16Params p) {
+    constexpr int BM = 128, BN = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][A image | B image]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const Gather& g = p.g;
+
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    const int mf0 = tile_m * BM, cb0 = tile_n * BN;
+    const int zs = blockIdx.z;
+    const int row_begin = zs * p.rows_per_split;
+    const int row_end = min(p.M, row_begin + p.rows_per_split);
+    const int nsteps = max(0, (row_end - row_begin + TN16_BK - 1) / TN16_BK);
+
+    // staging role: pixel rows 16 j + 4 w + prow of the K tile, channel chunk `ch` (fixed: the swizzle of those rows
+    // depends on prow and w only)
+    const int prow = lane >> 4;
+    const int ch = (lane & 15) ^ ((prow << 2) | w);
+    const int mf = mf0 + 8 * ch;
+    int a_kh = 0, a_kw = 0, a_c = mf;
+    if (MODE != GATHER_PLAIN) {
+        const int tap = mf / p.Ca;
+        a_c = mf - tap * p.Ca;
+        a_kh = tap / g.k;
+        a_kw = tap - a_kh * g.k;
+    }
+    const bool a_ok = mf < p.Mf;
+    const int cb = cb0 + 8 * ch;
+    const bool b_ok = cb < p.Cb;
+    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
+    const __bf16* Bb = reinterpret_cast<const __bf16*>(p.Bv);
+    const void* zero = reinterpret_cast<const void*>(g_zero_page);
+    int m_next = row_begin + 4 * w + prow;          // pixel of instruction j = 0 of the next K tile
+
+    auto stage = [&](int buf) {
+        unsigned char* sa = smem + buf * (2 * TN16_TILE) + (4 * w) * 256;
+        unsigned char* sb = sa + TN16_TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m_next + 16 * j;
+            const void* srca = zero;
+            const void* srcb = zero;
+            if (m < row_end) {
+                if (a_ok) {
+                    int64_t pix;
+                    if (MODE == GATHER_PLAIN) {
+                        pix = m;
+                    } else {
+                        int b, ho, wo;
+                        if (p.pow2) {
+                            wo = m & (g.Wq - 1);
+                            const int r = m >> p.wq_shift;
+                            ho = r & (g.Hq - 1);
+                            b = r >> p.hq_shift;
+                        } else {
+                            wo = m % g.Wq;
+                            const int r = m / g.Wq;
+                            ho = r % g.Hq;
+                            b = r / g.Hq;
+                        }
+                        const int hs = conv_src(ho, a_kh, g.stride, g.pad, g.reflect, g.Hs);
+                        const int ws = conv_src(wo, a_kw, g.stride, g.pad, g.reflect, g.Ws);
+                        pix = (hs >= 0 && ws >= 0) ? ((int64_t)b * g.Hs + hs) * g.Ws + ws : -1;
+                    }
+                    if (pix >= 0) srca = Ab + pix * g.ld + a_c;
+                }
+                if (b_ok) srcb = Bb + (int64_t)m * p.b_ld + cb;
+            }
+            glds16(srca, sa + j * 16 * 256);
+            glds16(srcb, sb + j * 16 * 256);
+        }
+        m_next += TN16_BK;
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed-read addresses (buffer 0, k-step 0): lane -> k block lane >> 5, 16-channel group (lane >> 4) & 1,
+    // block row q = (lane & 15) >> 2, column quad pq = lane & 3; read jj covers pixels 8 kblk + 4 jj .. + 3
+    const int kblk = lane >> 5, g16 = (lane >> 4) & 1, q = (lane & 15) >> 2, pq = lane & 3;
+    const uint32_t lds0 = static_cast<uint32_t>(
+        reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem));
+    uint32_t a_ad[2][2], b_ad[2][2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int row = 8 * kblk + 4 * jj + q;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a_ad[i][jj] = lds0 + tr16_swz(row, 4 * (wm * 2 + i) + 2 * g16 + (pq >> 1)) + 8 * (pq & 1);
+            b_ad[i][jj] = lds0 + TN16_TILE + tr16_swz(row, 4 * (wn * 2 + i) + 2 * g16 + (pq >> 1)) + 8 * (pq & 1);
+        }
+    }
+    auto operand = [&](uint32_t lo_addr, uint32_t hi_addr) {
+        const s16x4v lo = lds_tr16(lo_addr), hi = lds_tr16(hi_addr);
+        const s16x8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8_t, v);
+    };
+
+    if (nsteps > 0) stage(0);
+    __syncthreads();
+    for (int it = 0; it < nsteps; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nsteps) stage(cur ^ 1);
+        const uint32_t bufoff = (uint32_t)cur * (2u * TN16_TILE);
+#pragma unroll
+        for (int s = 0; s < TN16_BK / 16; ++s) {
+            bf16x8_t a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = operand(a_ad[i][0] + bufoff + 4096 * s, a_ad[i][1] + bufoff + 4096 * s);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = operand(b_ad[j][0] + bufoff + 4096 * s, b_ad[j][1] + bufoff + 4096 * s);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float* obase = p.out + (int64_t)zs * p.slab_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mf0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= p.Mf) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = cb0 + wn * 64 + 32 * j + (lane & 31);
+                if (col < p.Cb) obase[(int64_t)row * p.out_ld + col] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// transpose of tf.pad(REFLECT) (ops.py:82): fold the gradient on the padded grid back onto the image
+// ------------------------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(256) void reflect_fold_kernel(const void* __restrict__ dxp_, void* __restrict__ dx_, int N,
+                                                           int H, int W, int C8, int Hp, int Wp, int pad,
+                                                           int accumulate) {
+    const int64_t total = (int64_t)N * H * W * C8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        int64_t t = i / C8;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        // padded positions that mirror onto h: h + pad, pad - h (h >= 1), 2 (H - 1) - h + pad (h <= H - 2)
+        int hs[3], ws[3], nh = 0, nw = 0;
+        hs[nh++] = h + pad;
+        if (h >= 1 && pad - h >= 0) hs[nh++] = pad - h;
+        if (h <= H - 2 && 2 * (H - 1) - h + pad < Hp && H > 1) hs[nh++] = 2 * (H - 1) - h + pad;
+        ws[nw++] = w + pad;
+        if (w >= 1 && pad - w >= 0) ws[nw++] = pad - w;
+        if (w <= W - 2 && 2 * (W - 1) - w + pad < Wp && W > 1) ws[nw++] = 2 * (W - 1) - w + pad;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int a = 0; a < nh; ++a)
+            for (int b = 0; b < nw; ++b) {
+                if (hs[a] >= Hp || ws[b] >= Wp) continue;
+                const int64_t off = ((((int64_t)n * Hp + hs[a]) * Wp + ws[b]) * C8 + c8) * 8;
+                if (F32) {
+                    const float* sp = reinterpret_cast<const float*>(dxp_) + off;
+                    const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(sp), v1 = *reinterpret_cast<const f32x4_t*>(sp + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j] += v0[j];
+                        acc[4 + j] += v1[j];
+                    }
+                } else {
+                    const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(dxp_) + off);
+                    acc[0] += bf16_lo(r.x); acc[1] += bf16_hi(r.x); acc[2] += bf16_lo(r.y); acc[3] += bf16_hi(r.y);
+                    acc[4] += bf16_lo(r.z); acc[5] += bf16_hi(r.z); acc[6] += bf16_lo(r.w); acc[7] += bf16_hi(r.w);
+                }
+            }
+        if (F32) {
+            float* o = reinterpret_cast<float*>(dx_) + i * 8;
+            f32x4_t v0 = {acc[0], acc[1], acc[2], acc[3]}, v1 = {acc[4], acc[5], acc[6], acc[7]};
+            if (accumulate) {
+                v0 += *reinterpret_cast<const f32x4_t*>(o);
+                v1 += *reinterpret_cast<const f32x4_t*>(o + 4);
+            }
+            *reinterpret_cast<f32x4_t*>(o) = v0;
+            *reinterpret_cast<f32x4_t*>(o + 4) = v1;
+        } else {
+            __bf16* o = reinterpret_cast<__bf16*>(dx_) + i * 8;
+            if (accumulate) {
+                const uint4 r = *reinterpret_cast<const uint4*>(o);
+                acc[0] += bf16_lo(r.x); acc[1] += bf16_hi(r.x); acc[2] += bf16_lo(r.y); acc[3] += bf16_hi(r.y);
+                acc[4] += bf16_lo(r.z); acc[5] += bf16_hi(r.z); acc[6] += bf16_lo(r.w); acc[7] += bf16_hi(r.w);
+            }
+            uint4 r;
+            r.x = pack_bf16x2(acc[0], acc[1]);
+            r.y = pack_bf16x2(acc[2], acc[3]);
+            r.z = pack_bf16x2(acc[4], acc[5]);
+            r.w = pack_bf16x2(acc[6], acc[7]);
+            *reinterpret_cast<uint4*>(o) = r;
+        }
+    }
+}
+
+int launch_reflect_fold(const void* dxp, void* dx, int f32, int N, int H, int W, int C, int Hp, int Wp, int pad_lo,
+                        int accumulate, hipStream_t s) {
+    BG_REQUIRE(C % 8 == 0, "reflect fold: C %% 8 != 0");
+    const int64_t total = (int64_t)N * H * W * (C / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (f32)
+        hipLaunchKernelGGL((reflect_fold_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, dxp, dx, N, H, W, C / 8, Hp,
+                           Wp, pad_lo, accumulate);
+    else
+        hipLaunchKernelGGL((reflect_fold_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, dxp, dx, N, H, W, C / 8,
+                           Hp, Wp, pad_lo, accumulate);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct NN16Plan {
+    int tn, splitk;
+};
+
+static int nn16_steps_min(const NN16Params& p, int mode) {
+    int per_axis = p.g.k;
+    if (mode == GATHER_TCONV && p.g.pstep > 1) per_axis = max(1, p.g.k / p.g.stride);
+    return (per_axis * per_axis * (p.C >> 3) + 7) >> 3;
+}
+
+static NN16Plan plan_nn16(const NN16Params& p, int mode, int zdim, bool allow_split) {
+    NN16Plan pl;
+    // N tile: the width in {128, 96, 64, 32} that wastes the fewest padded columns (ties: the wider one)
+    int best = 4, best_waste = 1 << 30;
+    for (int tn = 4; tn >= 1; --tn) {
+        const int bn = 32 * tn;
+        const int waste = (p.N + bn - 1) / bn * bn - p.N;
+        if (waste < best_waste) {
+            best_waste = waste;
+            best = tn;
+        }
+    }
+    pl.tn = best;
+    pl.splitk = 1;
+    const int64_t tiles = (int64_t)((p.M + NN16_BM - 1) / NN16_BM) * ((p.N + 32 * pl.tn - 1) / (32 * pl.tn)) * zdim;
+    const int steps = nn16_steps_min(p, mode);
+    static const int want = getenv("BG_NN16_WANT") ? atoi(getenv("BG_NN16_WANT")) : 512;   // 2 blocks per CU
+    if (allow_split && tiles < want && steps >= 8) {
+        int sk = (int)((want + tiles - 1) / tiles);
+        if (sk > steps / 4) sk = steps / 4;
+        if (sk > 16) sk = 16;
+        if (sk > 1) pl.splitk = sk;
+    }
+    return pl;
+}
+
+size_t nn16_workspace_bytes(const NN16Params& p, int mode, int zdim, int64_t out_elems) {
+    const NN16Plan pl = plan_nn16(p, mode, zdim, true);
+    return pl.splitk > 1 ? (size_t)pl.splitk * out_elems * sizeof(float) : 0;
+}
+
+template <int TN, int MODE>
+static int launch_nn16_inst(const NN16Params& p, dim3 grid, hipStream_t s) {
+    constexpr int lds = nn16_lds_bytes(TN);
+    static bool attr_done = false;          // > 64 KB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_done) {
+        if (lds > 49152 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&nn16_kernel<TN, MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            set_error("nn16: cannot raise the dynamic LDS limit to %d bytes", lds);
+            return BG_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((nn16_kernel<TN, MODE>), grid, dim3(256), lds, s, p);
+    return BG_OK;
+}
+
+template <int MODE>
+static int launch_nn16_mode(const NN16Params& p, int tn, dim3 grid, hipStream_t s) {
+    switch (tn) {
+        case 1: return launch_nn16_inst<1, MODE>(p, grid, s);
+        case 2: return launch_nn16_inst<2, MODE>(p, grid, s);
+        case 3: return launch_nn16_inst<3, MODE>(p, grid, s);
+        default: return launch_nn16_inst<4, MODE>(p, grid, s);
+    }
+}
+
+int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, size_t ws_bytes, hipStream_t s) {
+    BG_REQUIRE(p.C % 8 == 0 && p.N % 8 == 0 && p.g.ld % 8 == 0 && p.out_ld % 8 == 0,
+               "bf16-resident conv: channel counts must be multiples of 8 (C=%d N=%d)", p.C, p.N);
+    BG_REQUIRE((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(p.out) & 15) == 0,
+               "bf16-resident conv: tensors must be 16-byte aligned");
+    NN16Plan pl = plan_nn16(p, mode, zdim, ws != nullptr);
+    if (pl.splitk > 1 && ws_bytes < (size_t)pl.splitk * out_elems * sizeof(float)) pl.splitk = 1;
+    p.splitk = pl.splitk;
+    p.slabs = reinterpret_cast<float*>(ws);
+    p.slab_stride = out_elems;
+    const int bn = 32 * pl.tn;
+    p.tiles_m = (p.M + NN16_BM - 1) / NN16_BM;
+    p.tiles_n = (p.N + bn - 1) / bn;
+    dim3 grid(p.tiles_m * p.tiles_n, 1, zdim * p.splitk);
+    p.zfold = 0;
+    if (mode == GATHER_TCONV && zdim > 1 && p.splitk == 1 && p.g.k % p.g.stride == 0) {
+        p.zfold = zdim;                     // the phases of one M tile gather the same input rows: same XCD
+        grid = dim3(p.tiles_m * p.tiles_n * zdim, 1, 1);
+    }
+    int rc;
+    if (mode == GATHER_CONV)
+        rc = launch_nn16_mode<GATHER_CONV>(p, pl.tn, grid, s);
+    else
+        rc = launch_nn16_mode<GATHER_TCONV>(p, pl.tn, grid, s);
+    if (rc) return rc;
+    BG_LAUNCH_CHECK();
+    if (pl.splitk > 1) {
+        const int64_t n8 = out_elems / 8;
+        int blocks = (int)((n8 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(nn16_slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slabs, p.out, p.bias, p.alpha, n8,
+                           p.N, pl.splitk, out_elems, p.accumulate, p.out_f32);
+        BG_LAUNCH_CHECK();
+    }
+    return BG_OK;
+}
+
+static void plan_tn16(TN16Params& p) {
+    const int64_t tiles = (int64_t)((p.Mf + 127) / 128) * ((p.Cb + 127) / 128);
+    static const int want = getenv("BG_TN16_WANT") ? atoi(getenv("BG_TN16_WANT")) : 1024;
+    int sk = (int)((want + tiles - 1) / tiles);
+    const int max_sk = (p.M + 4 * TN16_BK - 1) / (4 * TN16_BK);      // at least 256 pixels per split
+    if (sk > max_sk) sk = max_sk;
+    if (sk < 1) sk = 1;
+    if (sk > 512) sk = 512;
+    int rps = (p.M + sk - 1) / sk;
+    rps = (rps + TN16_BK - 1) / TN16_BK * TN16_BK;
+    p.splitk = (p.M + rps - 1) / rps;
+    p.rows_per_split = rps;
+}
+
+size_t tn16_workspace_bytes(const TN16Params& p0) {
+    TN16Params p = p0;
+    plan_tn16(p);
+    return p.splitk > 1 ? (size_t)p.splitk * p.Mf * p.Cb * sizeof(float) : 0;
+}
+
+int launch_tn16(TN16Params& p, int mode, float* final_out, void* ws, size_t ws_bytes, hipStream_t s) {
+    BG_REQUIRE(p.Ca % 8 == 0 && p.Cb % 8 == 0 && p.g.ld % 8 == 0 && p.b_ld % 8 == 0,
+               "bf16-resident wgrad: channel counts must be multiples of 8 (Ca=%d Cb=%d)", p.Ca, p.Cb);
+    BG_REQUIRE((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.Bv) & 15) == 0,
+               "bf16-resident wgrad: tensors must be 16-byte aligned");
+    plan_tn16(p);
+    const int64_t total = (int64_t)p.Mf * p.Cb;
+    if (p.splitk > 1 && (ws == nullptr || ws_bytes < (size_t)p.splitk * total * sizeof(float) || p.out_ld != p.Cb)) {
+        p.splitk = 1;
+        p.rows_per_split = (p.M + TN16_BK - 1) / TN16_BK * TN16_BK;
+    }
+    if (p.splitk > 1) {
+        p.out = reinterpret_cast<float*>(ws);
+        p.slab_stride = total;
+    } else {
+        p.out = final_out;
+        p.slab_stride = 0;
+    }
+    p.tiles_m = (p.Mf + 127) / 128;
+    p.tiles_n = (p.Cb + 127) / 128;
+    p.pow2 = 0;
+    if (mode != GATHER_PLAIN && (p.g.Wq & (p.g.Wq - 1)) == 0 && (p.g.Hq & (p.g.Hq - 1)) == 0) {
+        p.pow2 = 1;
+        p.wq_shift = __builtin_ctz(p.g.Wq);
+        p.hq_shift = __builtin_ctz(p.g.Hq);
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, 1, p.splitk);
+    constexpr int lds = 4 * TN16_TILE;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16_kernel<GATHER_CONV>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16_kernel<GATHER_PLAIN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    if (mode == GATHER_CONV)
+        hipLaunchKernelGGL((tn16_kernel<GATHER_CONV>), grid, dim3(256), lds, s, p);
+    else
+        hipLaunchKernelGGL((tn16_kernel<GATHER_PLAIN>), grid, dim3(256), lds, s, p);
+    BG_LAUNCH_CHECK();
+    if (p.splitk > 1) {
+        launch_slab_reduce(reinterpret_cast<const float*>(ws), final_out, total, p.splitk, total, s);
+        BG_LAUNCH_CHECK();
+    }
+    return BG_OK;
+}
+
+}  // namespace bg

@@ -68,13 +68,11 @@ __device__ __forceinline__ void mma_tile_bf16(const __bf16* __restrict__ as, con
 // ------------------------------------------------------------------------------------------
 // NN kernel, bf16 compute (vector path only: C % 4 == 0, 16-byte aligned operands)
 // ------------------------------------------------------------------------------------------
-// SRC16: both operands are read from bf16 copies (p.A16 / p.B16, same element offsets as the fp32 tensors):
-// half the L2 -> LDS bytes per tile and no conversion in the loop.  Requires C % 8 == 0, N % 8 == 0, !MIRROR.
 // BTR (only !BT, TN == 2): the [k][n] weight tile stays k-major in LDS (32 rows of 128 bf16, swizzled like the wgrad
 // kernel's images) and the B operand is read through ds_read_b64_tr_b16 instead of being transposed by the staging code.
-template <int TM, int TN, bool BT, int MODE, bool MIRROR, bool SRC16 = false, bool BTR = false>
+template <int TM, int TN, bool BT, int MODE, bool MIRROR, bool BTR = false>
 __global__ __launch_bounds__(256) void nn_kernel_bf16(const NNParams p) {
-    static_assert(!BTR || (!BT && TN == 2 && !SRC16), "BTR: non-BT weights, 128-wide tile, fp32 sources");
+    static_assert(!BTR || (!BT && TN == 2), "BTR: non-BT weights, 128-wide tile");
     constexpr int WN = 2;
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AITEMS = BM * 4 / 256;            // (row, k8) items per thread
@@ -159,15 +157,6 @@ __global__ __launch_bounds__(256) void nn_kernel_bf16(const NNParams p) {
     float4 ra[AITEMS][2];
     constexpr int BREG = BT ? BITEMS_T * 2 : BITEMS_N * 4;
     float4 rb[BREG];
-    uint4 ra16[AITEMS];                       // SRC16: 8 bf16 per item
-    uint4 rb16[BT ? BITEMS_T : 1];            // SRC16, BT: 8 bf16 per item
-    uint2 rb16n[BT ? 1 : BITEMS_N * 4];       // SRC16, !BT: 4 bf16 (along n) per k row of a patch
-    const __bf16* A16 = reinterpret_cast<const __bf16*>(p.A16);
-    const __bf16* B16 = reinterpret_cast<const __bf16*>(p.B16);
-    if (SRC16 && MODE == GATHER_PLAIN) {
-        A16 += (int64_t)zo * p.strideA;
-        B16 += (int64_t)zo * p.strideB;
-    }
 
     auto load_tile = [&]() {
         const int kh = kh0 + l_ih * kstep, kw = kw0 + l_iw * kstep;
@@ -177,41 +166,7 @@ __global__ __launch_bounds__(256) void nn_kernel_bf16(const NNParams p) {
             need_off = false;
         }
         const int c0 = (l_chunk * kci + l_ic) * BKB;
-        if constexpr (SRC16) {
-#pragma unroll
-            for (int i = 0; i < AITEMS; ++i) {
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (aoff[i][0] >= 0 && c0 + a_k8 < p.C)
-                    v = *reinterpret_cast<const uint4*>(A16 + aoff[i][0] + c0 + a_k8);
-                ra16[i] = v;
-            }
-            const __bf16* wt16 = B16 + (int64_t)(kh * g.k + kw) * p.tap_stride;
-            if (BT) {
-#pragma unroll
-                for (int i = 0; i < BITEMS_T; ++i) {
-                    const int n = n0 + (t >> 2) + 64 * i;
-                    const int c = c0 + a_k8;
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (n < p.N && c < p.C) v = *reinterpret_cast<const uint4*>(wt16 + (int64_t)n * p.ldn + c);
-                    rb16[i] = v;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < BITEMS_N; ++i) {
-                    const int idx = t + 256 * i;
-                    const int k4 = idx & 7, nq = idx >> 3;
-                    const int n = n0 + nq * 4;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int c = c0 + k4 * 4 + j;
-                        uint2 v = make_uint2(0u, 0u);
-                        if (idx < BPATCH && c < p.C && n < p.N)
-                            v = *reinterpret_cast<const uint2*>(wt16 + (int64_t)c * p.ldk + n);
-                        rb16n[i * 4 + j] = v;
-                    }
-                }
-            }
-        } else {
+        {
 #pragma unroll
         for (int i = 0; i < AITEMS; ++i) {
 #pragma unroll
@@ -285,42 +240,6 @@ __global__ __launch_bounds__(256) void nn_kernel_bf16(const NNParams p) {
     auto store_tile = [&](int buf) {
         __bf16* as = As[buf];
         __bf16* bs = Bs[buf];
-        if constexpr (SRC16) {
-#pragma unroll
-            for (int i = 0; i < AITEMS; ++i) {
-                const int r = (t >> 2) + 64 * i;
-                *reinterpret_cast<uint4*>(as + r * LROW + a_k8) = ra16[i];
-            }
-            if (BT) {
-#pragma unroll
-                for (int i = 0; i < BITEMS_T; ++i) {
-                    const int n = (t >> 2) + 64 * i;
-                    *reinterpret_cast<uint4*>(bs + n * LROW + a_k8) = rb16[i];
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < BITEMS_N; ++i) {
-                    const int idx = t + 256 * i;
-                    if (idx < BPATCH) {
-                        const int k4 = idx & 7, nq = idx >> 3;
-                        // rows k..k+3 hold (n0..n3) as 16-bit values: transpose 4x4 of halves
-                        const uint2 r0 = rb16n[i * 4], r1 = rb16n[i * 4 + 1], r2 = rb16n[i * 4 + 2], r3 = rb16n[i * 4 + 3];
-                        uint32_t* base = reinterpret_cast<uint32_t*>(bs + (nq * 4) * LROW + k4 * 4);
-                        constexpr int RW = LROW / 2;            // dwords per LDS row
-                        // n0: low halves of .x ; n1: high halves of .x ; n2: low of .y ; n3: high of .y
-                        base[0] = (r0.x & 0xffffu) | (r1.x << 16);
-                        base[1] = (r2.x & 0xffffu) | (r3.x << 16);
-                        base[RW] = (r0.x >> 16) | (r1.x & 0xffff0000u);
-                        base[RW + 1] = (r2.x >> 16) | (r3.x & 0xffff0000u);
-                        base[2 * RW] = (r0.y & 0xffffu) | (r1.y << 16);
-                        base[2 * RW + 1] = (r2.y & 0xffffu) | (r3.y << 16);
-                        base[3 * RW] = (r0.y >> 16) | (r1.y & 0xffff0000u);
-                        base[3 * RW + 1] = (r2.y >> 16) | (r3.y & 0xffff0000u);
-                    }
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < AITEMS; ++i) {
             const int r = (t >> 2) + 64 * i;

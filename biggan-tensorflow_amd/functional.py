@@ -9,7 +9,60 @@ import torch
 from torch.autograd import Function
 
 from . import hip
-from .hip import f32, i32, stream, check, lib, workspace
+from .hip import f32, i32, act, dt, stream, check, lib, workspace
+
+BF16 = torch.bfloat16
+
+
+class Precision:
+    """Arithmetic / storage policy, applied per call through the descriptors (no library-wide state).
+
+    compute   arithmetic of conv / transposed-conv launches on fp32 tensors: hip.COMPUTE_F32 (the reference's
+              precision, ops.py:14) or hip.COMPUTE_BF16 (bf16 MFMA, operands rounded while staged)
+    gemm_bf16 plain GEMMs with M, N, K >= 128 (the regulariser's Gram matrices) on the bf16 MFMA as well
+    resident  BASELINE configs 3-5: activations between ops are bf16 tensors in HBM and every spectrally
+              normalised conv kernel carries two packed bf16 copies (csrc/igemm16.hip)"""
+    compute = hip.COMPUTE_F32
+    gemm_bf16 = False
+    resident = False
+    name = "fp32"
+
+
+def set_precision(mode):
+    """'fp32' (default) | 'bf16-staged' (fp32 tensors, bf16 MFMA) | 'bf16' (bf16-resident activations)."""
+    if mode in (None, "", "fp32", "f32"):
+        Precision.compute, Precision.gemm_bf16, Precision.resident, Precision.name = hip.COMPUTE_F32, False, False, "fp32"
+    elif mode == "bf16-staged":
+        Precision.compute, Precision.gemm_bf16, Precision.resident, Precision.name = hip.COMPUTE_BF16, True, False, mode
+    elif mode == "bf16":
+        Precision.compute, Precision.gemm_bf16, Precision.resident, Precision.name = hip.COMPUTE_BF16, True, True, mode
+    else:
+        raise ValueError("precision %r: expected fp32, bf16-staged or bf16" % (mode,))
+
+
+def cast(x, dtype):
+    """Element-type conversion (RNE) by a HIP kernel; returns x itself when nothing changes."""
+    if x.dtype == dtype:
+        return x
+    x = _c(x)
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib().bg_cast(act(x), dt(x), act(y), dt(y), x.numel(), stream()))
+    return y
+
+
+def weight_packs(w):
+    """(pack_p, pack_t): the bf16 K-contiguous copies of a conv / transposed-conv kernel [k,k,A,B]: pack_p keeps the
+    variable's order [k*k][A][B], pack_t is [k*k][B][A].  Spectrally normalised kernels get them from the
+    multi-tensor power iteration (SnBatch); anything else is packed per call."""
+    pp = getattr(w, "bg_pack_p", None)
+    if pp is not None:
+        return pp, w.bg_pack_t
+    w = _c(w)
+    k2, A, B = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
+    pp = torch.empty((k2, A, B), dtype=BF16, device=w.device)
+    pt = torch.empty((k2, B, A), dtype=BF16, device=w.device)
+    check(lib().bg_weight_pack(f32(w), k2, A, B, act(pp), act(pt), stream()))
+    return pp, pt
 
 
 # ------------------------------------------------------------------------------------------
@@ -22,6 +75,18 @@ def _c(t):
 def axpby(x, a, y, b):
     """y = a*x + b*y (in place on y)."""
     check(lib().bg_axpby(f32(x), float(a), f32(y), float(b), x.numel(), stream()))
+    return y
+
+
+def add(a, b, out=None):
+    """a + b on tensors of one element type (fp32 or bf16)."""
+    if b.dtype != a.dtype:
+        b = cast(b, a.dtype)
+    y = torch.empty_like(a) if out is None else out
+    if a.dtype == torch.float32:
+        check(lib().bg_add(f32(a), f32(b), f32(y), a.numel(), stream()))
+    else:
+        check(lib().bg_lincomb_t(act(a), None, 1.0, act(b), 1.0, act(y), dt(a), a.numel(), stream()))
     return y
 
 
@@ -79,14 +144,24 @@ def param_grad(t, needed, producer):
 
 
 def _bias_grad(dy2d, out):
-    check(lib().bg_bias_grad(f32(dy2d), f32(out), dy2d.shape[0], dy2d.shape[1], stream()))
+    if dy2d.dtype == torch.float32:
+        check(lib().bg_bias_grad(f32(dy2d), f32(out), dy2d.shape[0], dy2d.shape[1], stream()))
+    else:
+        check(lib().bg_bias_grad_t(act(dy2d), dt(dy2d), f32(out), dy2d.shape[0], dy2d.shape[1], stream()))
 
 
 # ------------------------------------------------------------------------------------------
 # conv / transposed conv
 # ------------------------------------------------------------------------------------------
+def _resident_ok(x, cin, cout):
+    return x.dtype == BF16 and cin % 8 == 0 and cout % 8 == 0
+
+
 class Conv2dFn(Function):
-    """tf.pad(REFLECT)+tf.nn.conv2d(VALID)+bias_add (ops.py:82,94-98) / zero 'SAME'."""
+    """tf.pad(REFLECT)+tf.nn.conv2d(VALID)+bias_add (ops.py:82,94-98) / zero 'SAME'.
+
+    fp32 x: the fp32-tensor kernels (fp32 or bf16 MFMA per Precision.compute), fp32 y.
+    bf16 x: the bf16-resident kernels (packed weights, csrc/igemm16.hip); y is bf16 unless ``out_dtype`` says fp32."""
 
     # The direct kernels for <= 4 INPUT channels (bg_thinconv_*) are correct but, as measured in round 1
     # (128 x 128 x 3 -> 64, stride 2, batch 128: fwd 251 us / dgrad 1489 us / wgrad 210 us), slower than the
@@ -95,15 +170,29 @@ class Conv2dFn(Function):
     use_thin = False
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad_lo, Ho, Wo, pad_mode):
+    def forward(ctx, x, w, bias, stride, pad_lo, Ho, Wo, pad_mode, out_dtype=None):
         x = _c(x)
-        w = _c(w)
         N, H, W_, Cin = x.shape
         k, _, cin2, Cout = w.shape
         assert cin2 == Cin, (x.shape, w.shape)
-        d = hip.conv_desc(N, H, W_, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode)
-        y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         L = lib()
+        ctx.resident = _resident_ok(x, Cin, Cout)
+        ctx.in_dtype = x.dtype
+        if x.dtype == BF16 and not ctx.resident:
+            x = cast(x, torch.float32)         # (odd channel counts / the 3-channel head: fp32-tensor kernels)
+        if ctx.resident:
+            ydt = out_dtype or BF16
+            d = hip.conv_desc(N, H, W_, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode, hip.COMPUTE_BF16, hip.BF16,
+                              hip.BF16 if ydt == BF16 else hip.F32, 1)
+            y = torch.empty((N, Ho, Wo, Cout), dtype=ydt, device=x.device)
+            ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, d, x.device)
+            check(L.bg_conv2d_fwd(d, act(x), act(weight_packs(w)[1]), f32(bias), None, act(y), 0, f32(ws), nb, stream()))
+            ctx.desc, ctx.rgb, ctx.thin = d, False, False
+            ctx.x, ctx.w, ctx.bias = x, w, bias
+            return y
+        w = _c(w)
+        d = hip.conv_desc(N, H, W_, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode, Precision.compute)
+        y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         ctx.rgb = bool(L.bg_rgbconv_supported(d))      # <= 3 output channels: direct HBM-bound kernels
         ctx.thin = Conv2dFn.use_thin and (not ctx.rgb) and bool(L.bg_thinconv_supported(d))
         if ctx.rgb:
@@ -123,6 +212,25 @@ class Conv2dFn(Function):
         d, x, w, bias = ctx.desc, ctx.x, ctx.w, ctx.bias
         L = lib()
         dx = None
+        db = None
+        if bias is not None:
+            db = param_grad(bias, ctx.needs_input_grad[2], lambda out: _bias_grad(dy.view(-1, d.Cout), out))
+        if ctx.resident:
+            dyb = cast(dy, BF16)               # (fp32 when the consumer asked for an fp32 output)
+            db16 = hip.conv_desc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.k, d.stride, d.pad_lo, d.pad_mode,
+                                 hip.COMPUTE_BF16, hip.BF16, hip.BF16, 1)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                ws, nb = hip.scratch(L.bg_conv2d_dgrad_workspace_bytes, db16, x.device)
+                check(L.bg_conv2d_dgrad(db16, act(dyb), act(weight_packs(w)[0]), None, act(dx), 0, f32(ws), nb, stream()))
+
+            def wg16(out):
+                nb = L.bg_conv2d_wgrad_workspace_bytes(db16)
+                ws = workspace(nb, x.device)
+                check(L.bg_conv2d_wgrad(db16, act(x), act(dyb), f32(out), f32(ws), nb, stream()))
+            dw = param_grad(w, ctx.needs_input_grad[1], wg16)
+            ctx.x = ctx.w = ctx.bias = None
+            return dx, dw, db, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if ctx.rgb:
@@ -148,11 +256,10 @@ class Conv2dFn(Function):
             ws = workspace(nb, x.device)
             check(L.bg_conv2d_wgrad(d, f32(x), f32(dy), f32(out), f32(ws), nb, stream()))
         dw = param_grad(w, ctx.needs_input_grad[1], wg)
-        db = None
-        if bias is not None:
-            db = param_grad(bias, ctx.needs_input_grad[2], lambda out: _bias_grad(dy.view(-1, d.Cout), out))
         ctx.x = ctx.w = ctx.bias = None
-        return dx, dw, db, None, None, None, None, None
+        if dx is not None:
+            dx = cast(dx, ctx.in_dtype)
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class Deconv2dFn(Function):
@@ -161,21 +268,33 @@ class Deconv2dFn(Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad_lo, accumulate_into):
         x = _c(x)
-        w = _c(w)
         N, H, W_, Cin = x.shape
         k, _, Cout, cin2 = w.shape
         assert cin2 == Cin, (x.shape, w.shape)
-        d = hip.conv_desc(N, H, W_, Cin, H * stride, W_ * stride, Cout, k, stride, pad_lo, hip.PAD_ZERO)
+        ctx.resident = _resident_ok(x, Cin, Cout)
+        ctx.in_dtype = x.dtype
+        if x.dtype == BF16 and not ctx.resident:
+            x = cast(x, torch.float32)
+        ydt = BF16 if ctx.resident else torch.float32
+        if ctx.resident:
+            d = hip.conv_desc(N, H, W_, Cin, H * stride, W_ * stride, Cout, k, stride, pad_lo, hip.PAD_ZERO,
+                              hip.COMPUTE_BF16, hip.BF16, hip.BF16, 1)
+        else:
+            w = _c(w)
+            d = hip.conv_desc(N, H, W_, Cin, H * stride, W_ * stride, Cout, k, stride, pad_lo, hip.PAD_ZERO,
+                              Precision.compute)
         if accumulate_into is not None:
             y = accumulate_into          # residual sum fused into the epilogue: y += deconv(x)
+            assert y.dtype == ydt, (y.dtype, ydt)
             ctx.mark_dirty(y)
             acc = 1
         else:
-            y = torch.empty((N, H * stride, W_ * stride, Cout), dtype=torch.float32, device=x.device)
+            y = torch.empty((N, H * stride, W_ * stride, Cout), dtype=ydt, device=x.device)
             acc = 0
         L = lib()
         ws, nb = hip.scratch(L.bg_deconv2d_fwd_workspace_bytes, d, x.device)
-        check(L.bg_deconv2d_fwd(d, f32(x), f32(w), f32(bias), None, f32(y), acc, f32(ws), nb, stream()))
+        wk = weight_packs(w)[0] if ctx.resident else w
+        check(L.bg_deconv2d_fwd(d, act(x), act(wk), f32(bias), None, act(y), acc, f32(ws), nb, stream()))
         ctx.desc = d
         ctx.x, ctx.w, ctx.bias = x, w, bias
         ctx.acc = acc
@@ -187,21 +306,26 @@ class Deconv2dFn(Function):
         d, x, w, bias = ctx.desc, ctx.x, ctx.w, ctx.bias
         L = lib()
         dx = None
+        if ctx.resident:
+            dy = cast(dy, BF16)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             ws, nb = hip.scratch(L.bg_deconv2d_dgrad_workspace_bytes, d, x.device)
-            check(L.bg_deconv2d_dgrad(d, f32(dy), f32(w), None, f32(dx), 0, f32(ws), nb, stream()))
+            wk = weight_packs(w)[1] if ctx.resident else w
+            check(L.bg_deconv2d_dgrad(d, act(dy), act(wk), None, act(dx), 0, f32(ws), nb, stream()))
 
         def wg(out):
             nb = L.bg_deconv2d_wgrad_workspace_bytes(d)
             ws = workspace(nb, x.device)
-            check(L.bg_deconv2d_wgrad(d, f32(x), f32(dy), f32(out), f32(ws), nb, stream()))
+            check(L.bg_deconv2d_wgrad(d, act(x), act(dy), f32(out), f32(ws), nb, stream()))
         dw = param_grad(w, ctx.needs_input_grad[1], wg)
         db = None
         if bias is not None:
             db = param_grad(bias, ctx.needs_input_grad[2], lambda out: _bias_grad(dy.view(-1, d.Cout), out))
         ctx.x = ctx.w = ctx.bias = None
         dacc = dy if ctx.acc else None
+        if dx is not None:
+            dx = cast(dx, ctx.in_dtype)
         return dx, dw, db, None, None, dacc
 
 
@@ -211,7 +335,9 @@ class Deconv2dFn(Function):
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=1, sA=0, sB=0, sC=0,
          bias=None, alpha_dev=None, accumulate=False):
     """Raw bg_gemm launch on preallocated tensors (row-major, explicit leading dimensions)."""
-    d = hip.BgGemmDesc(M, N, K, int(transA), int(transB), lda, ldb, ldc, batch, sA, sB, sC)
+    bf16 = Precision.gemm_bf16 and M >= 128 and N >= 128 and K >= 128
+    d = hip.BgGemmDesc(M, N, K, int(transA), int(transB), lda, ldb, ldc, batch, sA, sB, sC,
+                       hip.COMPUTE_BF16 if bf16 else hip.COMPUTE_F32, 0)
     L = lib()
     nb = L.bg_gemm_workspace_bytes(d)
     ws = workspace(nb, C.device) if nb else None
@@ -394,6 +520,10 @@ class SnBatch:
             rows_tot += (rows + 3) // 4 * 4
         self.wn_flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.gwn_flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        # bf16-resident path: every 4-D (conv / transposed-conv) kernel whose two channel counts are multiples of 8
+        # also gets its two packed bf16 copies, written by the same normalisation launch
+        packed = [Precision.resident and w.dim() == 4 and w.shape[2] % 8 == 0 and w.shape[3] % 8 == 0 for w in self.w]
+        self.pack_flat = torch.zeros(2 * off if any(packed) else 0, dtype=BF16, device=dev)
         self.v_flat = torch.zeros(rows_tot, dtype=torch.float32, device=dev)
         self.sigma = torch.zeros(n, dtype=torch.float32, device=dev)
         self.ws_bytes = ws_off
@@ -422,6 +552,11 @@ class SnBatch:
             it.sigma = self.sigma.data_ptr() + 4 * i
             it.w_norm, it.g_wnorm, it.dw = wn.data_ptr(), wn.bg_grad.data_ptr(), dw.data_ptr()
             it.ws_offset, it.rows, it.cols = ws_offs[i], self.rows[i], self.cols[i]
+            if packed[i]:
+                k2, A, B = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
+                wn.bg_pack_p = self.pack_flat.narrow(0, 2 * offs[i], w.numel()).view(k2, A, B)
+                wn.bg_pack_t = self.pack_flat.narrow(0, 2 * offs[i] + w.numel(), w.numel()).view(k2, B, A)
+                it.pack_p, it.pack_t, it.taps = wn.bg_pack_p.data_ptr(), wn.bg_pack_t.data_ptr(), k2
             for t in (w, self.u[i], dw):
                 if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
                     raise RuntimeError("SnBatch needs contiguous CUDA fp32 tensors")
@@ -471,8 +606,10 @@ class BnActFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, alpha, moving_mean, moving_var, momentum, eps, unbiased_mv, is_training,
-                reduce_fn, world, renorm=None):
+                reduce_fn, world, renorm=None, out_dtype=None):
         x = _c(x)
+        ydt = out_dtype or x.dtype
+        typed = x.dtype != torch.float32 or ydt != torch.float32
         N, H, W_, C = x.shape
         HW = H * W_
         per_sample = int(gamma.dim() == 2)
@@ -483,7 +620,10 @@ class BnActFn(Function):
         count = float(N * HW * world)
         if is_training:
             sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
-            check(L.bg_bn_stats(f32(x), hip.ptr(sums), N * HW, C, stream()))
+            if typed:
+                check(L.bg_bn_stats_t(act(x), dt(x), hip.ptr(sums), N * HW, C, stream()))
+            else:
+                check(L.bg_bn_stats(f32(x), hip.ptr(sums), N * HW, C, stream()))
             if reduce_fn is not None:
                 reduce_fn(sums)
             if renorm is not None:          # corrections first: they read the running statistics before any update
@@ -499,7 +639,7 @@ class BnActFn(Function):
         else:
             # inference: population statistics (ops.py:643)
             check(L.bg_bn_population(f32(moving_mean), f32(moving_var), eps, f32(mean), f32(rstd), C, stream()))
-        y = torch.empty_like(x)
+        y = torch.empty(x.shape, dtype=ydt, device=dev)
         gamma_c, beta_c = _c(gamma), _c(beta)
         ctx.renorm_rd = None
         if renorm is not None and is_training:
@@ -508,8 +648,13 @@ class BnActFn(Function):
                                          gamma_c.numel() // C, C, stream()))
             gamma_c, beta_c = g_eff, b_eff
             ctx.renorm_rd = (r_, d_)
-        check(L.bg_bn_apply_act_fwd(f32(x), f32(mean), f32(rstd), f32(gamma_c), f32(beta_c), per_sample,
-                                    f32(alpha), f32(y), N, HW, C, stream()))
+        if typed:
+            check(L.bg_bn_apply_act_fwd_t(act(x), dt(x), f32(mean), f32(rstd), f32(gamma_c), f32(beta_c), per_sample,
+                                          f32(alpha), act(y), dt(y), N, HW, C, stream()))
+        else:
+            check(L.bg_bn_apply_act_fwd(f32(x), f32(mean), f32(rstd), f32(gamma_c), f32(beta_c), per_sample,
+                                        f32(alpha), f32(y), N, HW, C, stream()))
+        ctx.typed = typed
         ctx.x, ctx.mean, ctx.rstd = x, mean, rstd
         ctx.gamma, ctx.beta, ctx.alpha = gamma, beta, alpha
         ctx.gamma_c, ctx.beta_c = gamma_c, beta_c
@@ -529,8 +674,12 @@ class BnActFn(Function):
         dev = x.device
         ps = ctx.per_sample
         part = torch.empty((3, N, C), dtype=torch.float32, device=dev)
-        check(L.bg_bn_apply_act_bwd_reduce(f32(x), f32(dy), f32(mean), f32(rstd), f32(ctx.gamma_c), f32(ctx.beta_c),
-                                           ps, f32(alpha), f32(part), N, HW, C, stream()))
+        if ctx.typed:
+            check(L.bg_bn_apply_act_bwd_reduce_t(act(x), dt(x), act(dy), dt(dy), f32(mean), f32(rstd), f32(ctx.gamma_c),
+                                                 f32(ctx.beta_c), ps, f32(alpha), f32(part), N, HW, C, stream()))
+        else:
+            check(L.bg_bn_apply_act_bwd_reduce(f32(x), f32(dy), f32(mean), f32(rstd), f32(ctx.gamma_c), f32(ctx.beta_c),
+                                               ps, f32(alpha), f32(part), N, HW, C, stream()))
         gshape = (N, C) if ps else (C,)
         dgamma = torch.empty(gshape, dtype=torch.float32, device=dev)
         dbeta = torch.empty(gshape, dtype=torch.float32, device=dev)
@@ -551,8 +700,12 @@ class BnActFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(L.bg_bn_apply_act_bwd_dx(f32(x), f32(dy), f32(mean), f32(rstd), f32(ctx.gamma_c), f32(ctx.beta_c),
-                                           ps, f32(alpha), f32(cm), f32(dx), N, HW, C, stream()))
+            if ctx.typed:
+                check(L.bg_bn_apply_act_bwd_dx_t(act(x), dt(x), act(dy), dt(dy), f32(mean), f32(rstd), f32(ctx.gamma_c),
+                                                 f32(ctx.beta_c), ps, f32(alpha), f32(cm), act(dx), N, HW, C, stream()))
+            else:
+                check(L.bg_bn_apply_act_bwd_dx(f32(x), f32(dy), f32(mean), f32(rstd), f32(ctx.gamma_c), f32(ctx.beta_c),
+                                               ps, f32(alpha), f32(cm), f32(dx), N, HW, C, stream()))
 
         def deliver(t, needed, g):
             if not needed:
@@ -565,7 +718,7 @@ class BnActFn(Function):
         db = deliver(beta, ctx.needs_input_grad[2], dbeta)
         da = deliver(alpha, ctx.needs_input_grad[3], dalpha) if alpha is not None else None
         ctx.x = None
-        return dx, dg, db, da, None, None, None, None, None, None, None, None, None
+        return dx, dg, db, da, None, None, None, None, None, None, None, None, None, None
 
 
 class PReluFn(Function):
@@ -576,7 +729,10 @@ class PReluFn(Function):
         x = _c(x)
         C = x.shape[-1]
         y = torch.empty_like(x)
-        check(lib().bg_prelu_fwd(f32(x), f32(alpha), f32(y), x.numel() // C, C, stream()))
+        if x.dtype == torch.float32:
+            check(lib().bg_prelu_fwd(f32(x), f32(alpha), f32(y), x.numel() // C, C, stream()))
+        else:
+            check(lib().bg_prelu_fwd_t(act(x), dt(x), f32(alpha), act(y), dt(y), x.numel() // C, C, stream()))
         ctx.x, ctx.alpha = x, alpha
         return y
 
@@ -588,13 +744,20 @@ class PReluFn(Function):
         rows = x.numel() // C
         L = lib()
         dx = None
+        f32s = x.dtype == torch.float32 and dy.dtype == torch.float32
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(L.bg_prelu_bwd(f32(x), f32(dy), f32(alpha), f32(dx), None, rows, C, stream()))
+            if f32s:
+                check(L.bg_prelu_bwd(f32(x), f32(dy), f32(alpha), f32(dx), None, rows, C, stream()))
+            else:
+                check(L.bg_prelu_bwd_t(act(x), dt(x), act(dy), dt(dy), f32(alpha), act(dx), None, rows, C, stream()))
 
         def prod(out):
             out.zero_()
-            check(L.bg_prelu_bwd(f32(x), f32(dy), f32(alpha), None, f32(out), rows, C, stream()))
+            if f32s:
+                check(L.bg_prelu_bwd(f32(x), f32(dy), f32(alpha), None, f32(out), rows, C, stream()))
+            else:
+                check(L.bg_prelu_bwd_t(act(x), dt(x), act(dy), dt(dy), f32(alpha), None, f32(out), rows, C, stream()))
         da = param_grad(alpha, ctx.needs_input_grad[1], prod)
         ctx.x = None
         return dx, da
@@ -608,8 +771,11 @@ class MaxPool2Fn(Function):
     def forward(ctx, x):
         x = _c(x)
         N, H, W_, C = x.shape
-        y = torch.empty((N, H // 2, W_ // 2, C), dtype=torch.float32, device=x.device)
-        check(lib().bg_maxpool2_fwd(f32(x), f32(y), N, H, W_, C, stream()))
+        y = torch.empty((N, H // 2, W_ // 2, C), dtype=x.dtype, device=x.device)
+        if x.dtype == torch.float32:
+            check(lib().bg_maxpool2_fwd(f32(x), f32(y), N, H, W_, C, stream()))
+        else:
+            check(lib().bg_maxpool2_fwd_t(act(x), act(y), dt(x), N, H, W_, C, stream()))
         ctx.x = x
         return y
 
@@ -619,7 +785,10 @@ class MaxPool2Fn(Function):
         x = ctx.x
         N, H, W_, C = x.shape
         dx = torch.empty_like(x)
-        check(lib().bg_maxpool2_bwd(f32(x), f32(dy), f32(dx), N, H, W_, C, stream()))
+        if x.dtype == torch.float32:
+            check(lib().bg_maxpool2_bwd(f32(x), f32(dy), f32(dx), N, H, W_, C, stream()))
+        else:
+            check(lib().bg_maxpool2_bwd_t(act(x), act(cast(dy, x.dtype)), act(dx), dt(x), N, H, W_, C, stream()))
         ctx.x = None
         return dx
 
@@ -672,16 +841,23 @@ class SumPoolFn(Function):
         x = _c(x)
         N, H, W_, C = x.shape
         y = torch.empty((N, C), dtype=torch.float32, device=x.device)
-        check(lib().bg_sum_pool_fwd(f32(x), f32(y), N, H * W_, C, stream()))
+        if x.dtype == torch.float32:
+            check(lib().bg_sum_pool_fwd(f32(x), f32(y), N, H * W_, C, stream()))
+        else:
+            check(lib().bg_sum_pool_fwd_t(act(x), dt(x), f32(y), N, H * W_, C, stream()))
         ctx.shape = x.shape
+        ctx.xdt = x.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy = _c(dy)
         N, H, W_, C = ctx.shape
-        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
-        check(lib().bg_sum_pool_bwd(f32(dy), f32(dx), N, H * W_, C, stream()))
+        dx = torch.empty(ctx.shape, dtype=ctx.xdt, device=dy.device)
+        if ctx.xdt == torch.float32:
+            check(lib().bg_sum_pool_bwd(f32(dy), f32(dx), N, H * W_, C, stream()))
+        else:
+            check(lib().bg_sum_pool_bwd_t(f32(dy), act(dx), dt(dx), N, H * W_, C, stream()))
         return dx
 
 
@@ -709,13 +885,25 @@ class AddFn(Function):
     @staticmethod
     def forward(ctx, a, b):
         a, b = _c(a), _c(b)
-        y = torch.empty_like(a)
-        check(lib().bg_add(f32(a), f32(b), f32(y), a.numel(), stream()))
-        return y
+        return add(a, b)
 
     @staticmethod
     def backward(ctx, dy):
         return dy, dy
+
+
+class CastFn(Function):
+    """Element-type conversion between the fp32 and the bf16 parts of a bf16-resident network (the image layers and
+    the attention core stay fp32); the gradient is converted back."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return cast(_c(dy), ctx.src), None
 
 
 class ForkFn(Function):
@@ -734,10 +922,9 @@ class ForkFn(Function):
             return None, None
         if len(gs) == 1:
             return gs[0], None
-        out = torch.empty_like(gs[0])
-        check(lib().bg_add(f32(gs[0]), f32(gs[1]), f32(out), out.numel(), stream()))
+        out = add(gs[0], gs[1])
         for g in gs[2:]:
-            axpby(g, 1.0, out, 1.0)
+            out = add(out, g, out=out)
         return out, None
 
 
@@ -747,8 +934,14 @@ class ScaleAddFn(Function):
     @staticmethod
     def forward(ctx, o, gamma, x):
         o, x = _c(o), _c(x)
+        ctx.o_dtype = o.dtype
+        if o.dtype != x.dtype:
+            o = cast(o, x.dtype)
         y = torch.empty_like(x)
-        check(lib().bg_scale_add(f32(o), f32(gamma), f32(x), f32(y), x.numel(), stream()))
+        if x.dtype == torch.float32:
+            check(lib().bg_scale_add(f32(o), f32(gamma), f32(x), f32(y), x.numel(), stream()))
+        else:
+            check(lib().bg_lincomb_t(act(o), f32(gamma), 0.0, act(x), 1.0, act(y), dt(x), x.numel(), stream()))
         ctx.o, ctx.gamma = o, gamma
         return y
 
@@ -760,13 +953,21 @@ class ScaleAddFn(Function):
         do = None
         if ctx.needs_input_grad[0]:
             do = torch.empty_like(o)
-            check(L.bg_scale_dev(f32(dy), f32(gamma), f32(do), dy.numel(), stream()))
+            if dy.dtype == torch.float32:
+                check(L.bg_scale_dev(f32(dy), f32(gamma), f32(do), dy.numel(), stream()))
+            else:
+                check(L.bg_lincomb_t(act(dy), f32(gamma), 0.0, None, 0.0, act(do), dt(dy), dy.numel(), stream()))
 
         def prod(out):
             out.zero_()
-            check(L.bg_dot(f32(dy), f32(o), f32(out), dy.numel(), stream()))
+            if dy.dtype == torch.float32:
+                check(L.bg_dot(f32(dy), f32(o), f32(out), dy.numel(), stream()))
+            else:
+                check(L.bg_dot_t(act(dy), act(o), dt(dy), f32(out), dy.numel(), stream()))
         dg = param_grad(gamma, ctx.needs_input_grad[1], prod)
         ctx.o = None
+        if do is not None:
+            do = cast(do, ctx.o_dtype)
         return do, dg, dy
 
 

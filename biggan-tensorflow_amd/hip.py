@@ -12,25 +12,31 @@ import torch
 
 _LIB = None
 LIB_NAME = "libbiggan_hip.so"
+ABI_VERSION = 2
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 PAD_REFLECT, PAD_ZERO = 0, 1
+F32, BF16 = 0, 1                       # BG_F32 / BG_BF16: element types of activation tensors
+COMPUTE_F32, COMPUTE_BF16 = 0, 1       # per-call arithmetic of the GEMM-shaped launches
 
 
 class BgConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in
-                ("N", "H", "W", "Cin", "Ho", "Wo", "Cout", "k", "stride", "pad_lo", "pad_mode")]
+                ("N", "H", "W", "Cin", "Ho", "Wo", "Cout", "k", "stride", "pad_lo", "pad_mode",
+                 "compute", "x_dtype", "y_dtype", "w_packed")]
 
 
 class BgGemmDesc(Structure):
     _fields_ = [("M", c_int32), ("N", c_int32), ("K", c_int32), ("transA", c_int32), ("transB", c_int32),
                 ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("batch", c_int32),
-                ("strideA", c_int64), ("strideB", c_int64), ("strideC", c_int64)]
+                ("strideA", c_int64), ("strideB", c_int64), ("strideC", c_int64),
+                ("compute", c_int32), ("reserved", c_int32)]
 
 
 class BgSnItem(Structure):
     _fields_ = [("w", c_void_p), ("u", c_void_p), ("v", c_void_p), ("sigma", c_void_p), ("w_norm", c_void_p),
-                ("g_wnorm", c_void_p), ("dw", c_void_p), ("ws_offset", c_int64), ("rows", c_int32), ("cols", c_int32)]
+                ("g_wnorm", c_void_p), ("dw", c_void_p), ("ws_offset", c_int64), ("rows", c_int32), ("cols", c_int32),
+                ("pack_p", c_void_p), ("pack_t", c_void_p), ("taps", c_int32), ("reserved", c_int32)]
 
 
 _P = c_void_p
@@ -43,8 +49,6 @@ SIGNATURES = {
     "bg_last_error": (c_char_p, []),
     "bg_target_arch": (c_char_p, []),
     "bg_png_unfilter": (c_int, [c_char_p, c_int, c_int, c_int, _P]),
-    "bg_set_gemm_compute": (None, [c_int]),
-    "bg_get_gemm_compute": (c_int, []),
     "bg_conv2d_fwd_workspace_bytes": (c_size_t, [_CD]),
     "bg_conv2d_fwd": (c_int, [_CD, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "bg_conv2d_dgrad_workspace_bytes": (c_size_t, [_CD]),
@@ -132,6 +136,23 @@ SIGNATURES = {
                                     c_int64, _P]),
     "bg_adam_tf_ema_step_dev": (c_int, [_P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int64,
                                         _P]),
+    "bg_cast": (c_int, [_P, c_int, _P, c_int, c_int64, _P]),
+    "bg_weight_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "bg_bn_stats_t": (c_int, [_P, c_int, _P, c_int64, c_int, _P]),
+    "bg_bn_apply_act_fwd_t": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "bg_bn_apply_act_bwd_reduce_t": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int,
+                                             _P]),
+    "bg_bn_apply_act_bwd_dx_t": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int,
+                                         _P]),
+    "bg_prelu_fwd_t": (c_int, [_P, c_int, _P, _P, c_int, c_int64, c_int, _P]),
+    "bg_prelu_bwd_t": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int64, c_int, _P]),
+    "bg_bias_grad_t": (c_int, [_P, c_int, _P, c_int64, c_int, _P]),
+    "bg_maxpool2_fwd_t": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bg_maxpool2_bwd_t": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bg_sum_pool_fwd_t": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
+    "bg_sum_pool_bwd_t": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "bg_lincomb_t": (c_int, [_P, _P, c_float, _P, c_float, _P, c_int, c_int64, _P]),
+    "bg_dot_t": (c_int, [_P, _P, c_int, _P, c_int64, _P]),
     "bg_prof_enable": (None, [c_int]),
     "bg_prof_reset": (None, []),
     "bg_prof_collect": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
@@ -152,8 +173,9 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if L.bg_abi_version() != 1:
-            raise ImportError("libbiggan_hip.so ABI version %d != 1" % L.bg_abi_version())
+        if L.bg_abi_version() != ABI_VERSION:
+            raise ImportError("libbiggan_hip.so ABI version %d != %d (rebuild: python -c 'import __graft_entry__ as g; "
+                              "g.build()')" % (L.bg_abi_version(), ABI_VERSION))
         _LIB = L
     return _LIB
 
@@ -181,6 +203,22 @@ def f32(t):
     return ptr(t)
 
 
+def dt(t):
+    """BG_F32 / BG_BF16 code of a tensor's element type."""
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise RuntimeError("expected float32 or bfloat16, got %s" % t.dtype)
+
+
+def act(t):
+    """Device pointer of an activation tensor (fp32 or bf16)."""
+    if t is not None:
+        dt(t)
+    return ptr(t)
+
+
 def i32(t):
     if t is not None and t.dtype != torch.int32:
         raise RuntimeError("expected int32, got %s" % t.dtype)
@@ -191,8 +229,9 @@ def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def conv_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode):
-    return BgConvDesc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode)
+def conv_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode, compute=COMPUTE_F32, x_dtype=F32, y_dtype=F32,
+              w_packed=0):
+    return BgConvDesc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode, compute, x_dtype, y_dtype, w_packed)
 
 
 def workspace(nbytes, device):

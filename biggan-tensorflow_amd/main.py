@@ -54,9 +54,18 @@ FLAGS = [
 ]
 
 
+# Extensions of this build (not flags of the reference, kept out of FLAGS):
+#   --precision fp32        the reference's arithmetic (ops.py:14): fp32 tensors, fp32 MFMA          [default]
+#               bf16-staged fp32 tensors, conv / large GEMM operands rounded to bf16 while staged, fp32 accumulate
+#               bf16        BASELINE configs 3-5: bf16-resident activations + packed bf16 weights, fp32 accumulate,
+#                           fp32 master weights / optimiser / statistics
+#   the default can also be given by the environment variable BIGGAN_PRECISION
+EXTRA_FLAGS = [("precision", T, None)]
+
+
 def build_parser():
     parser = argparse.ArgumentParser(description="MI355X-native BigGAN training step (flag surface of the reference)")
-    for name, typ, default in FLAGS:
+    for name, typ, default in FLAGS + EXTRA_FLAGS:
         parser.add_argument("--" + name, type=typ, default=default)
     return parser
 
@@ -74,7 +83,11 @@ def check_args(args, make_dirs=True):
 
 
 def parse_args(argv=None, make_dirs=True):
-    return check_args(build_parser().parse_args(argv), make_dirs)
+    import os
+    args = build_parser().parse_args(argv)
+    if args.precision is None:
+        args.precision = os.environ.get("BIGGAN_PRECISION", "fp32")
+    return check_args(args, make_dirs)
 
 
 def main(argv=None):

@@ -154,6 +154,10 @@ class BigGAN(GANBase):
             else:
                 self.cls_loss_weights = [1.0] * self.n_labels
 
+        # arithmetic / storage policy (extension flag --precision): must be set before build_model() sizes the
+        # packed-weight buffers of the spectral-norm batches
+        self.precision = getattr(args, "precision", None) or "fp32"
+        Fn.set_precision(self.precision)
         self.store = store if store is not None else S.VariableStore(self.device, seed)
         S.set_default_store(self.store)
         self.pg = process_group
@@ -327,7 +331,7 @@ class BigGAN(GANBase):
                 ch = self.g_channels_for_block(b_i, len(counts))
                 ch_mul = ch_mul // 2
 
-            x = ops._bn_act(x, None, opt)                                              # BigGAN.py:491-492
+            x = ops._bn_act(x, None, opt, _out_fp32=True)                              # BigGAN.py:491-492
             x = conv(x, channels=self.c_dim, kernel=self.g_rgb_mix_kernel, stride=1, pad=1, use_bias=False, opt=opt,
                      scope='G_logit')                                                  # BigGAN.py:570
             x = tanh(x)                                                                # BigGAN.py:580
@@ -450,6 +454,7 @@ class BigGAN(GANBase):
 
     def _begin_run(self):
         S.set_default_store(self.store)       # several models may live in one process: ops resolve variables here
+        Fn.set_precision(self.precision)
         ops.begin_run(self._reduce_fn(), self.world, self.rank, getattr(self, "reg_owner", None))
 
     def _sn_prefetch(self, group, x):

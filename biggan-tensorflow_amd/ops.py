@@ -132,8 +132,23 @@ def encode_kernel_sizes(slices, ch_mul=1.0):
     raise NotImplementedError("mixed-kernel convolutions (ops.py:44) are outside the default hot path")
 
 
-def conv(x, channels, opt, kernel=4, stride=2, pad=0, dilation=1, use_bias=True, scope='conv_0'):
-    """ops.py:49-113."""
+def _to(x, dtype):
+    """Element-type conversion as a differentiable op (no-op when the type already matches)."""
+    if _is_meta(x) or x.dtype == dtype:
+        return x
+    return Fn.CastFn.apply(x, dtype)
+
+
+def _resident_out(y):
+    """bf16-resident mode: a large activation produced by the fp32-tensor kernels (the image layers) joins the bf16
+    part of the network."""
+    if Fn.Precision.resident and y.dtype == torch.float32 and y.dim() == 4 and y.shape[-1] % 8 == 0:
+        return Fn.CastFn.apply(y, torch.bfloat16)
+    return y
+
+
+def conv(x, channels, opt, kernel=4, stride=2, pad=0, dilation=1, use_bias=True, scope='conv_0', _out_dtype=None):
+    """ops.py:49-113.  ``_out_dtype`` (extension, bf16-resident mode): element type of the result."""
     with variable_scope(scope) as full_scope:
         if isinstance(kernel, str):
             raise NotImplementedError("mixed-kernel convolutions (ops.py:52-59) are outside the default hot path")
@@ -180,7 +195,8 @@ def conv(x, channels, opt, kernel=4, stride=2, pad=0, dilation=1, use_bias=True,
         if _is_dual(x):
             return Dual(Fn.Conv2dFn.apply(x.p, wk, bias, stride, pad_lo, Ho, Wo, pad_mode),
                         Fn.Conv2dFn.apply(x.t, wk, None, stride, pad_lo, Ho, Wo, pad_mode))
-        return Fn.Conv2dFn.apply(x, wk, bias, stride, pad_lo, Ho, Wo, pad_mode)
+        y = Fn.Conv2dFn.apply(x, wk, bias, stride, pad_lo, Ho, Wo, pad_mode, _out_dtype)
+        return y if _out_dtype is not None else _resident_out(y)
 
 
 def deconv(x, channels, opt, kernel=4, stride=2, padding='SAME', use_bias=True, scope='deconv_0', _accumulate_into=None):
@@ -201,7 +217,9 @@ def deconv(x, channels, opt, kernel=4, stride=2, padding='SAME', use_bias=True, 
             bias = get_variable("bias", [channels], initializer=S.constant_initializer(0.0))
         if _is_meta(x):
             return _meta((N, H * stride, W * stride, channels))
-        return Fn.Deconv2dFn.apply(x, wk, bias, stride, pad_lo, _accumulate_into)
+        if _accumulate_into is not None and _accumulate_into.dtype != x.dtype and x.dtype == torch.bfloat16:
+            _accumulate_into = _to(_accumulate_into, x.dtype)
+        return _resident_out(Fn.Deconv2dFn.apply(x, wk, bias, stride, pad_lo, _accumulate_into))
 
 
 def get_variable_with_custom_lr(name, shape, regularizer, lrmul):
@@ -495,10 +513,12 @@ def self_attention_2(x, channels, opt, scope='self_attention'):
     with variable_scope(scope):
         use_bias = opt.get("self_attention_bias", False)
         x_f, x_g, x_h, x = _fork(x, 4)
-        f = conv(x_f, channels // 8, kernel=1, stride=1, opt=opt, scope='f_conv', use_bias=use_bias)
+        # (bf16-resident mode: the attention core stays fp32 - its 1x1 producers write fp32 directly)
+        f32o = None if _is_meta(x) or _is_dual(x) or x.dtype == torch.float32 else torch.float32
+        f = conv(x_f, channels // 8, kernel=1, stride=1, opt=opt, scope='f_conv', use_bias=use_bias, _out_dtype=f32o)
         f = max_pooling(f)
-        g = conv(x_g, channels // 8, kernel=1, stride=1, opt=opt, scope='g_conv', use_bias=use_bias)
-        h = conv(x_h, channels // 2, kernel=1, stride=1, opt=opt, scope='h_conv', use_bias=use_bias)
+        g = conv(x_g, channels // 8, kernel=1, stride=1, opt=opt, scope='g_conv', use_bias=use_bias, _out_dtype=f32o)
+        h = conv(x_h, channels // 2, kernel=1, stride=1, opt=opt, scope='h_conv', use_bias=use_bias, _out_dtype=f32o)
         h = max_pooling(h)
         gamma = get_variable("gamma", [1], initializer=S.constant_initializer(0.0))
         if _is_meta(x):
@@ -507,8 +527,11 @@ def self_attention_2(x, channels, opt, scope='self_attention'):
             o = _attention_dual(hw_flatten(g), hw_flatten(f), hw_flatten(h))
             o = o.reshape(x.shape[0], x.shape[1], x.shape[2], channels // 2)
         else:
-            o = Fn.AttentionFn.apply(hw_flatten(g), hw_flatten(f), hw_flatten(h))     # softmax(g f^T) h
+            o = Fn.AttentionFn.apply(hw_flatten(_to(g, torch.float32)), hw_flatten(_to(f, torch.float32)),
+                                     hw_flatten(_to(h, torch.float32)))                # softmax(g f^T) h
             o = o.reshape(x.shape[0], x.shape[1], x.shape[2], channels // 2)
+            if x.dtype == torch.bfloat16 and (channels // 2) % 8 == 0 and channels % 8 == 0:
+                o = _to(o, torch.bfloat16)
         o = conv(o, channels, kernel=1, stride=1, opt=opt, scope='attn_conv', use_bias=use_bias)
         if _is_meta(x):
             return _meta(x.shape)
@@ -568,7 +591,7 @@ def avg_pooling(x):
         return _meta((x.shape[0], x.shape[1] // 2, x.shape[2] // 2, x.shape[3]))
     if _is_dual(x):
         return Dual(Fn.AvgPool2Fn.apply(x.p), Fn.AvgPool2Fn.apply(x.t))
-    return Fn.AvgPool2Fn.apply(x)
+    return _resident_out(Fn.AvgPool2Fn.apply(_to(x, torch.float32)))
 
 
 def up_sample(x, scale_factor=2):
@@ -577,7 +600,7 @@ def up_sample(x, scale_factor=2):
         raise NotImplementedError("up_sample scale_factor != 2")
     if _is_meta(x):
         return _meta((x.shape[0], x.shape[1] * 2, x.shape[2] * 2, x.shape[3]))
-    return Fn.UpSample2Fn.apply(x)
+    return _resident_out(Fn.UpSample2Fn.apply(_to(x, torch.float32)))
 
 
 ##################################################################################
@@ -681,7 +704,15 @@ def _act_alpha(act, x):
     return False, None
 
 
-def _bn_act(x, z, opt):
+def _bn_out_dtype(x, out_fp32):
+    """bf16-resident mode: batch-norm outputs feed convolutions, so they are written as bf16 (fp32 on request: the
+    3-channel RGB head reads fp32)."""
+    if _is_meta(x) or not Fn.Precision.resident:
+        return None
+    return torch.float32 if out_fp32 else torch.bfloat16
+
+
+def _bn_act(x, z, opt, _out_fp32=False):
     """(cond_)bn followed by opt['act'], fused into one apply kernel when the activation is PReLU/ReLU."""
     fused_types = ('bn', 'batch_norm', 'batch_norm_broken_renorm', 'batch_renorm')
     if opt.get("bn", {}).get("type", "bn") in fused_types and opt["act"] in (prelu, relu):
@@ -691,13 +722,13 @@ def _bn_act(x, z, opt):
                 return batch_renorm(x, opt=opt, scope='batch_renorm', _act=opt["act"])
             return condition_batch_renorm(x, z, opt=opt, scope='batch_renorm', _act=opt["act"])
         if z is None:
-            return batch_norm(x, opt=opt, scope=scope, _act=opt["act"])
+            return batch_norm(x, opt=opt, scope=scope, _act=opt["act"], _out_fp32=_out_fp32)
         return condition_batch_norm(x, z, opt=opt, scope=scope, _act=opt["act"])
     x = bn(x, opt=opt) if z is None else cond_bn(x, z, opt=opt)
     return opt["act"](x)
 
 
-def batch_norm(x, opt={}, scope='batch_norm', _act=None):
+def batch_norm(x, opt={}, scope='batch_norm', _act=None, _out_fp32=False):
     """ops.py:580-585: tf.layers.batch_normalization(momentum, epsilon=1e-5, training)."""
     C = x.shape[-1]
     with variable_scope(scope):
@@ -712,7 +743,7 @@ def batch_norm(x, opt={}, scope='batch_norm', _act=None):
         return _meta(x.shape)
     momentum = opt.get("bn", {}).get("momentum", 0.98)
     return Fn.BnActFn.apply(x, gamma, beta, alpha, mm, mv, momentum, 1e-05, True, bool(opt["is_training"]),
-                            _run.reduce_fn, _run.world)
+                            _run.reduce_fn, _run.world, None, _bn_out_dtype(x, _out_fp32))
 
 
 def normalize_renorm_clipping_params(renorm_clipping):
@@ -749,7 +780,7 @@ def batch_renorm(x, opt={}, scope='batch_renorm', _act=None):
                   rmin=clip["rmin"], rmax=clip["rmax"], dmax=clip["dmax"],
                   decay=opt.get("bn", {}).get("renorm_momentum", 0.9))
     return Fn.BnActFn.apply(x, gamma, beta, alpha, mm, mv, opt.get("bn", {}).get("momentum", 0.98), 1e-05, False,
-                            bool(opt["is_training"]), _run.reduce_fn, _run.world, renorm)
+                            bool(opt["is_training"]), _run.reduce_fn, _run.world, renorm, _bn_out_dtype(x, False))
 
 
 def condition_batch_norm(x, z, opt={}, scope='batch_norm', _act=None):
@@ -768,7 +799,7 @@ def condition_batch_norm(x, z, opt={}, scope='batch_norm', _act=None):
     if _is_meta(x):
         return _meta(x.shape)
     return Fn.BnActFn.apply(x, gamma, beta, alpha, test_mean, test_var, decay, epsilon, False,
-                            bool(opt["is_training"]), _run.reduce_fn, _run.world)
+                            bool(opt["is_training"]), _run.reduce_fn, _run.world, None, _bn_out_dtype(x, False))
 
 
 def condition_batch_renorm(x, z, opt={}, scope='batch_renorm', _act=None):
@@ -806,7 +837,7 @@ def condition_batch_renorm(x, z, opt={}, scope='batch_renorm', _act=None):
                   update=int(not shared), rmin=clip["rmin"], rmax=clip["rmax"], dmax=clip["dmax"],
                   decay=renorm_decay, fadein_decay=renorm_fadein_decay)
     return Fn.BnActFn.apply(x, gamma, beta, alpha, test_mean, test_var, test_decay, epsilon, False,
-                            bool(opt["is_training"]), _run.reduce_fn, _run.world, renorm)
+                            bool(opt["is_training"]), _run.reduce_fn, _run.world, renorm, _bn_out_dtype(x, False))
 
 
 def spectral_norm(w, iteration=1, _shape_only=False):

@@ -25,10 +25,16 @@
 extern "C" {
 #endif
 
-#define BG_ABI_VERSION 1
+#define BG_ABI_VERSION 2
 
 enum { BG_OK = 0, BG_ERR_ARG = 1, BG_ERR_LAUNCH = 2, BG_ERR_UNSUPPORTED = 3 };
 enum { BG_PAD_REFLECT = 0, BG_PAD_ZERO = 1 };
+/* element types of activation tensors (the "_t" entry points and the dtype fields of BgConvDesc) */
+enum { BG_F32 = 0, BG_BF16 = 1 };
+/* arithmetic of a GEMM-shaped launch, chosen PER CALL in its descriptor (no process-wide state):
+ *   BG_COMPUTE_F32  : v_mfma_f32_32x32x2_f32, exact fp32 FMA chain (the reference's precision, ops.py:14)
+ *   BG_COMPUTE_BF16 : bf16 MFMA with fp32 accumulation; fp32 operands are rounded to bf16 (RNE) while staged */
+enum { BG_COMPUTE_F32 = 0, BG_COMPUTE_BF16 = 1 };
 
 int         bg_abi_version(void);
 const char* bg_last_error(void);
@@ -50,20 +56,22 @@ typedef struct BgConvDesc {
     int32_t k, stride;
     int32_t pad_lo;            /* low padding (conv) / low crop (deconv)            */
     int32_t pad_mode;          /* BG_PAD_REFLECT (tf.pad REFLECT + VALID, ops.py:82) or BG_PAD_ZERO */
+    int32_t compute;           /* BG_COMPUTE_F32 / BG_COMPUTE_BF16 (fp32 tensors)                  */
+    int32_t x_dtype;           /* element type of the layer's INPUT-side tensor  (x, dx): BG_F32 / BG_BF16 */
+    int32_t y_dtype;           /* element type of the layer's OUTPUT-side tensor (y, dy)                    */
+    int32_t w_packed;          /* 1: w is a bf16 K-contiguous packed copy (see below), 0: the fp32 variable */
 } BgConvDesc;
 
-/* Compute precision of the conv / transposed-conv entry points (process-wide):
- *   0 = fp32 MFMA (default; the reference's precision, ops.py:14)
- *   1 = bf16 MFMA with fp32 accumulation: operands are rounded to bf16 (RNE) while they are staged
- *       into LDS; tensors in HBM, outputs, dense layers, attention and every other kernel stay fp32.
- *   2 = 1 + bg_gemm launches with M, N, K >= 128 (the regulariser's Gram matrices and their gradients).
- *   3 = 2 + (experimental) conv / transposed-conv forward and input-gradient launches read BOTH operands from
- *       whole-tensor bf16 copies made per call into library-owned device scratch (grow-only, used in stream order
- *       on one stream): the kernel variant a bf16-resident activation layout will use.  Same results as mode 1
- *       (RNE rounding happens in the copy instead of in the staging loop).  Measured in round 1: the kernel alone
- *       gains 5-23 % on the deep layers, the copies cost as much; not used by bench.py. */
-void bg_set_gemm_compute(int mode);
-int  bg_get_gemm_compute(void);
+/* The bf16-RESIDENT data path (BASELINE configs 3-5).  When the tensor a launch GATHERS from (x for the forward
+ * and the weight gradient, dy for the input gradient) is BG_BF16, the launch runs on the global_load_lds kernels
+ * of csrc/igemm16.hip: tiles go HBM -> LDS without passing through registers, so the weights must already be bf16
+ * with the reduction dimension contiguous (w_packed = 1):
+ *     forward of conv  : [k*k][Cout][Cin]      input gradient of conv  : [k*k][Cin][Cout]
+ *     forward of deconv: [k*k][Cout][Cin]      input gradient of deconv: [k*k][Cin][Cout]
+ * i.e. for each op one of the two copies bg_spectral_norm_batch_fwd writes next to w / sigma (BgSnItem::pack_p =
+ * the variable's own order, pack_t = the two inner axes swapped).  Channel counts must be multiples of 8.  The
+ * other tensor of the call may be bf16 or fp32 (its dtype field); weight gradients are always fp32.  With
+ * BG_PAD_REFLECT the input gradient is computed on the padded grid and folded back (scratch from ws). */
 
 /* Every MFMA GEMM entry point takes caller-provided scratch (ws, ws_bytes) sized by the matching
  * *_workspace_bytes(): it holds split-K partial slabs for layers whose output is too small to fill
@@ -71,30 +79,32 @@ int  bg_get_gemm_compute(void);
  * un-split (same result up to fp32 summation order). */
 
 /* tf.nn.conv2d (+ reflect tf.pad, + bias_add)                       ops.py:82,94-98
- *   y = alpha * conv(x, w) [+ bias] [+ y if accumulate]; alpha_dev (nullable) is a device scalar. */
+ *   y = alpha * conv(x, w) [+ bias] [+ y if accumulate]; alpha_dev (nullable) is a device scalar.
+ *   x, y: fp32, or the dtypes named by d->x_dtype / d->y_dtype; w: fp32 [k,k,Cin,Cout] or the packed bf16 copy. */
 size_t bg_conv2d_fwd_workspace_bytes(const BgConvDesc*);
-int bg_conv2d_fwd  (const BgConvDesc*, const float* x, const float* w, const float* bias,
-                    const float* alpha_dev, float* y, int accumulate,
+int bg_conv2d_fwd  (const BgConvDesc*, const void* x, const void* w, const float* bias,
+                    const float* alpha_dev, void* y, int accumulate,
                     void* ws, size_t ws_bytes, void* stream);
-/* gradient of the above w.r.t. x (reflect padding folded back)      autodiff of ops.py:82,94 */
+/* gradient of the above w.r.t. x (reflect padding folded back)      autodiff of ops.py:82,94
+ *   dy has d->y_dtype, dx has d->x_dtype */
 size_t bg_conv2d_dgrad_workspace_bytes(const BgConvDesc*);
-int bg_conv2d_dgrad(const BgConvDesc*, const float* dy, const float* w, const float* alpha_dev,
-                    float* dx, int accumulate, void* ws, size_t ws_bytes, void* stream);
-/* gradient w.r.t. w: dw[k,k,Cin,Cout] */
+int bg_conv2d_dgrad(const BgConvDesc*, const void* dy, const void* w, const float* alpha_dev,
+                    void* dx, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* gradient w.r.t. w: dw[k,k,Cin,Cout], always fp32 */
 size_t bg_conv2d_wgrad_workspace_bytes(const BgConvDesc*);
-int bg_conv2d_wgrad(const BgConvDesc*, const float* x, const float* dy, float* dw,
+int bg_conv2d_wgrad(const BgConvDesc*, const void* x, const void* dy, float* dw,
                     void* ws, size_t ws_bytes, void* stream);
 
 /* tf.nn.conv2d_transpose(SAME) (+ bias_add)                          ops.py:127-132 */
 size_t bg_deconv2d_fwd_workspace_bytes(const BgConvDesc*);
-int bg_deconv2d_fwd  (const BgConvDesc*, const float* x, const float* w, const float* bias,
-                      const float* alpha_dev, float* y, int accumulate,
+int bg_deconv2d_fwd  (const BgConvDesc*, const void* x, const void* w, const float* bias,
+                      const float* alpha_dev, void* y, int accumulate,
                       void* ws, size_t ws_bytes, void* stream);
 size_t bg_deconv2d_dgrad_workspace_bytes(const BgConvDesc*);
-int bg_deconv2d_dgrad(const BgConvDesc*, const float* dy, const float* w, const float* alpha_dev,
-                      float* dx, int accumulate, void* ws, size_t ws_bytes, void* stream);
+int bg_deconv2d_dgrad(const BgConvDesc*, const void* dy, const void* w, const float* alpha_dev,
+                      void* dx, int accumulate, void* ws, size_t ws_bytes, void* stream);
 size_t bg_deconv2d_wgrad_workspace_bytes(const BgConvDesc*);
-int bg_deconv2d_wgrad(const BgConvDesc*, const float* x, const float* dy, float* dw,
+int bg_deconv2d_wgrad(const BgConvDesc*, const void* x, const void* dy, float* dw,
                       void* ws, size_t ws_bytes, void* stream);
 
 /* Direct (vector-ALU, HBM-bound) path for k x k stride-1 convolutions with <= 3 output channels:
@@ -130,6 +140,8 @@ typedef struct BgGemmDesc {
     int32_t lda, ldb, ldc;
     int32_t batch;
     int64_t strideA, strideB, strideC;   /* elements between batch items */
+    int32_t compute;                     /* BG_COMPUTE_F32 / BG_COMPUTE_BF16 */
+    int32_t reserved;
 } BgGemmDesc;
 size_t bg_gemm_workspace_bytes(const BgGemmDesc*);
 int bg_gemm(const BgGemmDesc*, const float* A, const float* B, const float* bias,
@@ -180,6 +192,12 @@ typedef struct BgSnItem {
     float* dw;             /* bwd out: dL/dw */
     int64_t ws_offset;
     int32_t rows, cols;
+    /* bf16-resident path (optional, NULL otherwise): the weight seen as [taps][rows / taps][cols];
+     * pack_p[tap][r][c] = pack_t[tap][c][r] = bf16(w[tap][r][c] / sigma).  rows / taps and cols must be even. */
+    void* pack_p;
+    void* pack_t;
+    int32_t taps;
+    int32_t reserved;
 } BgSnItem;
 int bg_spectral_norm_batch_fwd(const BgSnItem* items_dev, int n_items, void* ws, size_t ws_bytes, void* stream);
 int bg_spectral_norm_batch_bwd(const BgSnItem* items_dev, int n_items, const uint64_t* enable_mask,
@@ -279,6 +297,42 @@ int bg_scale_dev(const float* x, const float* s_dev, float* y, int64_t n, void* 
 int bg_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
 int bg_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
 int bg_bias_grad(const float* dy, float* db, int64_t rows, int C, void* stream);         /* db[c] = sum_rows dy */
+
+/* --------------------------------------------------------------------------------------------
+ * bf16-resident data path (BASELINE configs 3-5): "_t" forms of the bandwidth-bound kernels above.  Activation
+ * tensors are fp32 or bf16 in HBM (dtype arguments: BG_F32 / BG_BF16), arithmetic is fp32 in registers, parameters,
+ * statistics and reductions stay fp32 / fp64.  x_dtype names the op's INPUT-side tensors (x, dx), y_dtype its
+ * OUTPUT-side tensors (y, dy).  C % 4 == 0 (8-byte bf16 accesses).  Same formulas and reference call sites as the
+ * fp32 entry points of the same name.
+ * ------------------------------------------------------------------------------------------ */
+int bg_cast(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, void* stream);
+/* the two packed bf16 copies of a conv kernel that is NOT spectrally normalised (see BgSnItem::pack_p / pack_t) */
+int bg_weight_pack(const float* w, int taps, int rows_per_tap, int cols, void* pack_p, void* pack_t, void* stream);
+int bg_bn_stats_t(const void* x, int x_dtype, double* sums, int64_t rows, int C, void* stream);
+int bg_bn_apply_act_fwd_t(const void* x, int x_dtype, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int per_sample, const float* alpha, void* y, int y_dtype,
+                          int N, int HW, int C, void* stream);
+int bg_bn_apply_act_bwd_reduce_t(const void* x, int x_dtype, const void* dy, int y_dtype, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, int per_sample,
+                                 const float* alpha, float* part, int N, int HW, int C, void* stream);
+int bg_bn_apply_act_bwd_dx_t(const void* x, int x_dtype, const void* dy, int y_dtype, const float* mean,
+                             const float* rstd, const float* gamma, const float* beta, int per_sample,
+                             const float* alpha, const float* cm, void* dx, int N, int HW, int C, void* stream);
+int bg_prelu_fwd_t(const void* x, int x_dtype, const float* alpha, void* y, int y_dtype, int64_t rows, int C,
+                   void* stream);
+/* dx (x_dtype, nullable) and / or dalpha (fp32 [C], accumulated: caller zeroes; nullable) */
+int bg_prelu_bwd_t(const void* x, int x_dtype, const void* dy, int y_dtype, const float* alpha, void* dx,
+                   float* dalpha, int64_t rows, int C, void* stream);
+int bg_bias_grad_t(const void* dy, int dtype, float* db, int64_t rows, int C, void* stream);
+int bg_maxpool2_fwd_t(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream);
+int bg_maxpool2_bwd_t(const void* x, const void* dy, void* dx, int dtype, int N, int H, int W, int C, void* stream);
+int bg_sum_pool_fwd_t(const void* x, int x_dtype, float* y, int N, int HW, int C, void* stream);
+int bg_sum_pool_bwd_t(const float* dy, void* dx, int x_dtype, int N, int HW, int C, void* stream);
+/* y = s * a + sb * b with s = *sa_dev (device scalar) when sa_dev != NULL, else sa; b may be NULL (y = s * a):
+ * residual adds, gamma * o + x (ops.py:490), scaling by a device scalar.  n % 4 == 0. */
+int bg_lincomb_t(const void* a, const float* sa_dev, float sa, const void* b, float sb, void* y, int dtype,
+                 int64_t n, void* stream);
+int bg_dot_t(const void* a, const void* b, int dtype, float* out_accum, int64_t n, void* stream);  /* out += <a,b> */
 
 /* --------------------------------------------------------------------------------------------
  * DiffAugment 'color,translation,cutout' (DiffAugment_tf.py:8-73), x [N,S,S,C] fp32.

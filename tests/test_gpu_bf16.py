@@ -1,7 +1,11 @@
-"""bf16-compute mode of the conv / transposed-conv kernels (bg_set_gemm_compute(1)): operands are
-rounded to bf16 while staged into LDS, accumulation is fp32.  Stated tolerance: relative L2 error
-<= 1e-2 against the float64 reference (bf16 has an 8-bit mantissa: unit round-off 2^-9 = 2e-3 per
-operand; measured errors are 2e-3..4e-3)."""
+"""bf16 arithmetic of the conv / transposed-conv kernels, chosen per call (functional.set_precision):
+
+  bf16-staged  fp32 tensors in HBM, operands rounded to bf16 while staged into LDS (igemm_bf16.h), fp32 accumulate
+  bf16         the bf16-RESIDENT path of BASELINE configs 3-5 (csrc/igemm16.hip): bf16 activations, packed bf16
+               weights, global_load_lds staging, fp32 accumulate, bf16 (or fp32) outputs
+
+Stated tolerance: relative L2 error <= 1e-2 against the float64 reference on the un-rounded inputs (bf16 has an
+8-bit mantissa: unit round-off 2^-9 = 2e-3 per operand; measured errors are 2e-3..5e-3)."""
 import numpy as np
 import pytest
 import torch
@@ -13,102 +17,208 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-2
 
 
-def cu(a, grad=False):
-    t = torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda")
+def cu(a, grad=False, dtype=torch.float32):
+    t = torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda").to(dtype)
     if grad:
         t.requires_grad_(True)
     return t
 
 
-@pytest.fixture(params=[1, 3])
-def bf16_mode(request):
-    """1: operands rounded while they are staged into LDS; 3: whole-operand bf16 copies + the bf16-source kernel."""
+def f64(t):
+    return t.detach().double().cpu().numpy()
+
+
+@pytest.fixture(params=["bf16-staged", "bf16"])
+def precision(request):
     import biggan_tensorflow_amd  # noqa: F401
-    from biggan_tensorflow_amd import hip
-    L = hip.lib()
-    L.bg_set_gemm_compute(request.param)
-    assert L.bg_get_gemm_compute() == request.param
-    yield
-    L.bg_set_gemm_compute(0)
-    assert L.bg_get_gemm_compute() == 0
+    from biggan_tensorflow_amd import functional as Fn
+    Fn.set_precision(request.param)
+    yield request.param
+    Fn.set_precision("fp32")
 
 
-def test_bf16_source_kernels_equal_staged_rounding():
-    """Mode 3 rounds the same values the same way (RNE) and accumulates in the same order as mode 1: bit-identical."""
-    import biggan_tensorflow_amd  # noqa: F401
-    from biggan_tensorflow_amd import hip, functional as Fn
-    L = hip.lib()
-    rng = np.random.default_rng(0)
-    x = cu(rng.standard_normal((4, 16, 16, 128)))
-    wc = cu(rng.standard_normal((3, 3, 128, 256)) * 0.05)
-    wd = cu(rng.standard_normal((4, 4, 64, 128)) * 0.05)
-    outs = {}
-    try:
-        for mode in (1, 3):
-            L.bg_set_gemm_compute(mode)
-            outs[mode] = (Fn.Conv2dFn.apply(x, wc, None, 1, 1, 16, 16, hip.PAD_REFLECT).clone(),
-                          Fn.Conv2dFn.apply(x, wc, None, 2, 1, 8, 8, hip.PAD_ZERO).clone(),
-                          Fn.Deconv2dFn.apply(x, wd, None, 2, 1, None).clone())
-    finally:
-        L.bg_set_gemm_compute(0)
-    for a, b in zip(outs[1], outs[3]):
-        assert torch.equal(a, b)
+def _act_dtype(mode):
+    return torch.bfloat16 if mode == "bf16" else torch.float32
 
 
-@pytest.mark.parametrize("N,H,Cin,Cout,k,s", [(2, 16, 64, 128, 3, 1), (2, 16, 64, 64, 3, 2), (4, 8, 128, 256, 3, 1),
-                                              (2, 32, 64, 64, 3, 1), (3, 8, 96, 192, 3, 2), (16, 4, 256, 256, 3, 1),
-                                              (4, 16, 128, 96, 3, 1),      # 128-wide tile, ragged N = 96 (ch = 96 nets)
-                                              (4, 16, 160, 200, 3, 1)])    # ragged N = 200 and Ca = 160 in the wgrad
-def test_conv_bf16(bf16_mode, N, H, Cin, Cout, k, s):
+CONV16 = [(2, 16, 64, 128, 3, 1), (2, 16, 64, 64, 3, 2), (4, 8, 128, 256, 3, 1),
+          (2, 32, 64, 64, 3, 1), (3, 8, 96, 192, 3, 2), (16, 4, 256, 256, 3, 1),
+          (4, 16, 128, 96, 3, 1),      # ragged N = 96 (ch = 96 nets): the 96-wide tile
+          (4, 16, 160, 200, 3, 1),     # ragged N = 200 and Ca = 160 in the wgrad
+          (2, 16, 96, 24, 1, 1),       # attention f / g 1x1 convs: N = 24 (32-wide tile), K = 96 (one and a half steps)
+          (2, 8, 8, 8, 3, 2),          # 8 channels: every 16-byte chunk is a different tap
+          (64, 4, 512, 512, 3, 1)]     # small map, long K: split-K slabs
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,k,s", CONV16)
+def test_conv_bf16(precision, N, H, Cin, Cout, k, s):
     from biggan_tensorflow_amd import functional as Fn, hip
     rng = np.random.default_rng(N + H + Cin + Cout)
     x = rng.standard_normal((N, H, H, Cin))
     w = rng.standard_normal((k, k, Cin, Cout)) * 0.1
+    pad = 1 if k == 3 else 0
     xt, wt = torch.tensor(x, requires_grad=True), torch.tensor(w, requires_grad=True)
-    xin = F.pad(xt.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect")
+    xin = xt.permute(0, 3, 1, 2)
+    if pad:
+        xin = F.pad(xin, (1, 1, 1, 1), mode="reflect")
     yr = F.conv2d(xin.contiguous(), wt.permute(3, 2, 0, 1).contiguous(), stride=s).permute(0, 2, 3, 1)
     g = rng.standard_normal(tuple(yr.shape))
     yr.backward(torch.tensor(g))
-    xc, wc = cu(x, True), cu(w, True)
-    y = Fn.Conv2dFn.apply(xc, wc, None, s, 1, yr.shape[1], yr.shape[1], hip.PAD_REFLECT)
-    y.backward(cu(g))
-    e = (rel_err(t2n(y), yr.detach().numpy()), rel_err(t2n(xc.grad), xt.grad.numpy()),
-         rel_err(t2n(wc.grad), wt.grad.numpy()))
+    dt = _act_dtype(precision)
+    xc, wc = cu(x, True, dt), cu(w, True)
+    y = Fn.Conv2dFn.apply(xc, wc, None, s, pad, yr.shape[1], yr.shape[1], hip.PAD_REFLECT)
+    assert y.dtype == dt and xc.dtype == dt
+    y.backward(cu(g, dtype=dt))
+    assert xc.grad.dtype == dt and wc.grad.dtype == torch.float32
+    e = (rel_err(f64(y), yr.detach().numpy()), rel_err(f64(xc.grad), xt.grad.numpy()),
+         rel_err(f64(wc.grad), wt.grad.numpy()))
     assert max(e) < TOL, e
     assert min(e) > 1e-5, ("bf16 path does not seem to be active", e)
 
 
 @pytest.mark.parametrize("N,H,Cin,Cout,k,s", [(2, 8, 128, 64, 4, 2), (2, 8, 64, 64, 3, 1), (2, 4, 256, 128, 4, 2),
                                               (2, 16, 96, 96, 3, 1), (8, 4, 192, 192, 4, 2),
-                                              (4, 16, 96, 128, 4, 2)])     # dgrad: 128-wide tile over N = Cin = 96
-def test_deconv_bf16(bf16_mode, N, H, Cin, Cout, k, s):
+                                              (4, 16, 96, 128, 4, 2),      # dgrad: N = Cin = 96
+                                              (2, 8, 64, 32, 3, 2),        # k3 s2: unequal stride phases, asymmetric SAME
+                                              (32, 4, 512, 512, 4, 2)])    # 4x4 map: split-K
+def test_deconv_bf16(precision, N, H, Cin, Cout, k, s):
     from biggan_tensorflow_amd import functional as Fn
     rng = np.random.default_rng(N + H + Cin + Cout + k)
     x = rng.standard_normal((N, H, H, Cin))
     w = rng.standard_normal((k, k, Cout, Cin)) * 0.1
     xt, wt = torch.tensor(x, requires_grad=True), torch.tensor(w, requires_grad=True)
-    yr = F.conv_transpose2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), stride=s, padding=1).permute(0, 2, 3, 1)
+    tot = max((H - 1) * s + k - s * H, 0)
+    pad_lo = tot // 2
+    yr = F.conv_transpose2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), stride=s, padding=0)
+    yr = yr[:, :, pad_lo:pad_lo + s * H, pad_lo:pad_lo + s * H].permute(0, 2, 3, 1)
     g = rng.standard_normal(tuple(yr.shape))
     yr.backward(torch.tensor(g))
-    xc, wc = cu(x, True), cu(w, True)
-    y = Fn.Deconv2dFn.apply(xc, wc, None, s, 1, None)
-    y.backward(cu(g))
-    e = (rel_err(t2n(y), yr.detach().numpy()), rel_err(t2n(xc.grad), xt.grad.numpy()),
-         rel_err(t2n(wc.grad), wt.grad.numpy()))
+    dt = _act_dtype(precision)
+    xc, wc = cu(x, True, dt), cu(w, True)
+    y = Fn.Deconv2dFn.apply(xc, wc, None, s, pad_lo, None)
+    assert y.dtype == dt
+    y.backward(cu(g, dtype=dt))
+    e = (rel_err(f64(y), yr.detach().numpy()), rel_err(f64(xc.grad), xt.grad.numpy()),
+         rel_err(f64(wc.grad), wt.grad.numpy()))
     assert max(e) < TOL, e
     assert min(e) > 1e-5, ("bf16 path does not seem to be active", e)
 
 
-def test_bf16_mode2_regulariser_and_large_gemm():
-    """bg_set_gemm_compute(2): the large plain GEMMs (Gram matrices of the ortho-cosine regulariser and
-    their gradients) run on the bf16 MFMA too; loss <= 2e-2, gradient <= 3e-2 relative to float64."""
-    import biggan_tensorflow_amd  # noqa: F401
+def test_resident_conv_exact_on_bf16_representable_data():
+    """With inputs that ARE bf16 numbers and an fp32 output, the resident kernels differ from float64 only by fp32
+    accumulation order (<= 2e-5): pins the gather / swizzle / K-flattening index math independently of rounding.
+    Covers zero 'SAME' padding (asymmetric for stride 2), bias, fp32 output and the fused residual accumulate."""
     from biggan_tensorflow_amd import functional as Fn, hip
-    from oracle import ref_ops as R
-    L = hip.lib()
-    L.bg_set_gemm_compute(2)
+    Fn.set_precision("bf16")
     try:
-        assert L.bg_get_gemm_compute() == 2
+        rng = np.random.default_rng(3)
+        for (N, H, Cin, Cout, k, s, mode) in [(2, 16, 96, 64, 3, 1, hip.PAD_REFLECT), (2, 16, 64, 96, 3, 2, hip.PAD_ZERO),
+                                              (3, 8, 32, 40, 1, 1, hip.PAD_REFLECT), (2, 12, 24, 16, 3, 1, hip.PAD_ZERO)]:
+            x = torch.tensor(rng.standard_normal((N, H, H, Cin))).bfloat16().double()
+            w = torch.tensor(rng.standard_normal((k, k, Cin, Cout)) * 0.1).bfloat16().double()
+            b = torch.tensor(rng.standard_normal(Cout))
+            pad = 1 if k == 3 else 0
+            xin = x.permute(0, 3, 1, 2)
+            Ho = -(-H // s) if mode == hip.PAD_ZERO else (H + 2 * pad - k) // s + 1
+            if mode == hip.PAD_REFLECT:
+                if pad:
+                    xin = F.pad(xin, (1, 1, 1, 1), mode="reflect")
+                pad_lo = pad
+            else:
+                tot = max((Ho - 1) * s + k - H, 0)
+                pad_lo = tot // 2
+                xin = F.pad(xin, (pad_lo, tot - pad_lo, pad_lo, tot - pad_lo))
+            yr = F.conv2d(xin.contiguous(), w.permute(3, 2, 0, 1).contiguous(), stride=s).permute(0, 2, 3, 1) + b
+            y = Fn.Conv2dFn.apply(x.float().cuda().bfloat16(), w.float().cuda(), b.float().cuda(), s, pad_lo, Ho, Ho, mode,
+                                  torch.float32)
+            assert y.dtype == torch.float32
+            assert rel_err(f64(y), yr.numpy()) < 2e-5, (N, H, Cin, Cout, k, s, mode)
+        # transposed conv with the residual sum fused into the epilogue (resblock_up, ops.py:250-266)
+        x = torch.tensor(rng.standard_normal((2, 8, 8, 64))).bfloat16().double()
+        w = torch.tensor(rng.standard_normal((4, 4, 32, 64)) * 0.1).bfloat16().double()
+        skip = torch.tensor(rng.standard_normal((2, 16, 16, 32))).bfloat16()
+        yr = F.conv_transpose2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), stride=2, padding=1).permute(0, 2, 3, 1)
+        yr = yr + skip.double()
+        acc = skip.cuda().clone()
+        y = Fn.Deconv2dFn.apply(x.float().cuda().bfloat16(), w.float().cuda(), None, 2, 1, acc)
+        assert y.dtype == torch.bfloat16 and y.data_ptr() == acc.data_ptr()
+        assert rel_err(f64(y), yr.numpy()) < 4e-3          # one bf16 rounding of the sum
+    finally:
+        Fn.set_precision("fp32")
+
+
+def test_spectral_norm_batch_writes_packed_bf16_copies():
+    """bf16-resident mode: the multi-tensor power iteration also writes pack_p = bf16(w / sigma) in the variable's
+    order and pack_t with the two inner axes swapped (BgSnItem::pack_p / pack_t)."""
+    from biggan_tensorflow_amd import functional as Fn
+    Fn.set_precision("bf16")
+    try:
+        g = torch.Generator(device="cuda").manual_seed(7)
+        ws = [torch.randn(3, 3, 96, 64, device="cuda", generator=g) * 0.05,
+              torch.randn(4, 4, 40, 72, device="cuda", generator=g) * 0.05,
+              torch.randn(1, 1, 200, 24, device="cuda", generator=g) * 0.05,
+              torch.randn(32, 96, device="cuda", generator=g) * 0.05,             # dense kernel: no packs
+              torch.randn(3, 3, 3, 64, device="cuda", generator=g) * 0.05]        # image layer (3 channels): no packs
+        us = [torch.randn(1, w.shape[-1], device="cuda", generator=g) for w in ws]
+        sb = Fn.SnBatch(list(zip(ws, us)))
+        wns = sb.forward()
+        for i, (w, wn) in enumerate(zip(ws, wns)):
+            sig = sb.sigma[i].item()
+            assert rel_err(t2n(wn), t2n(w) / sig) < 1e-6
+            if i >= 3:
+                assert getattr(wn, "bg_pack_p", None) is None
+                continue
+            k2 = w.shape[0] * w.shape[1]
+            ref = wn.view(k2, w.shape[2], w.shape[3]).bfloat16()
+            assert torch.equal(wn.bg_pack_p, ref)
+            assert torch.equal(wn.bg_pack_t, ref.transpose(1, 2).contiguous())
+        # a kernel that is not spectrally normalised is packed per call
+        pp, pt = Fn.weight_packs(ws[0])
+        assert torch.equal(pp, ws[0].view(9, 96, 64).bfloat16()) and torch.equal(pt, pp.transpose(1, 2).contiguous())
+    finally:
+        Fn.set_precision("fp32")
+
+
+def test_typed_elementwise_kernels_match_fp32_kernels():
+    """The "_t" kernels (bf16 / mixed element types) compute in fp32 registers: on bf16-representable inputs they equal
+    the fp32 kernels up to the final rounding of the output."""
+    from biggan_tensorflow_amd import functional as Fn
+    g = torch.Generator(device="cuda").manual_seed(11)
+    N, H, C = 3, 8, 24
+    x = torch.randn(N, H, H, C, device="cuda", generator=g).bfloat16()
+    dy = torch.randn(N, H, H, C, device="cuda", generator=g).bfloat16()
+    alpha = torch.rand(C, device="cuda", generator=g) * 0.3
+    gamma = torch.randn(N, C, device="cuda", generator=g)
+    beta = torch.randn(N, C, device="cuda", generator=g)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        xv = x.to(dt).requires_grad_(True)
+        a = alpha.clone().requires_grad_(True)
+        ga, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        mm, mv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        y = Fn.BnActFn.apply(xv, ga, be, a, mm, mv, 0.98, 1e-5, False, True, None, 1, None, dt)
+        y2 = Fn.PReluFn.apply(y, a)
+        y3 = Fn.MaxPool2Fn.apply(y2)
+        p = Fn.SumPoolFn.apply(y3)
+        (p * torch.arange(C, device="cuda").float()).sum().backward()
+        outs[dt] = (y.float(), y3.float(), p, xv.grad.float(), a.grad, ga.grad, mm)
+    for a_, b_ in zip(outs[torch.float32], outs[torch.bfloat16]):
+        assert rel_err(t2n(b_), t2n(a_)) < 1.5e-2
+    # cast round trip and the linear-combination kernels
+    y = Fn.cast(Fn.cast(x, torch.float32), torch.bfloat16)
+    assert torch.equal(y, x)
+    s = Fn.add(x, dy)
+    assert rel_err(f64(s), f64(x) + f64(dy)) < 4e-3
+
+
+def test_bf16_staged_regulariser_and_large_gemm():
+    """Precision.gemm_bf16: the large plain GEMMs (Gram matrices of the ortho-cosine regulariser and their gradients)
+    run on the bf16 MFMA too; loss <= 2e-2, gradient <= 3e-2 relative to float64."""
+    import biggan_tensorflow_amd  # noqa: F401
+    from biggan_tensorflow_amd import functional as Fn
+    from oracle import ref_ops as R
+    Fn.set_precision("bf16-staged")
+    try:
         rng = np.random.default_rng(5)
         for shape in [(3, 3, 256, 256), (4, 4, 128, 192), (184, 1024)]:
             w = rng.standard_normal(shape) * 0.05
@@ -132,21 +242,46 @@ def test_bf16_mode2_regulariser_and_large_gemm():
         Fn.gemm(cu(A2), cu(B2), C2, 384, 256, 512, 384, 256, 256, transA=True)
         assert 1e-5 < rel_err(t2n(C2), A2.T @ B2) < 1e-2
     finally:
-        L.bg_set_gemm_compute(0)
+        Fn.set_precision("fp32")
 
 
-def test_bf16_step_losses_close_to_fp32(bf16_mode):
-    """Whole D+G iteration in bf16-compute mode: losses within 2e-2 relative of the float64 oracle
-    (bf16 tolerance stated separately from the fp32 gate)."""
+@pytest.mark.parametrize("mode,img,ch,B", [("bf16-staged", 64, 16, 4), ("bf16", 64, 16, 4), ("bf16", 128, 96, 2)])
+def test_bf16_step_close_to_float64_oracle(mode, img, ch, B):
+    """Whole D op and G op in the bf16 modes against the float64 oracle: losses within 2e-2 relative (SURVEY section
+    8d: bf16 tolerance stated separately from the fp32 gate), generated images within 2e-2, every first-step gradient
+    tensor within 1e-1 relative L2 (bf16 activations AND bf16 activation gradients through ~20 layers; the scalar
+    attention gains and the exactly-zero f_conv bias gradient excepted).  The 128^2 / ch = 96 case is BASELINE
+    config 3's topology and channel widths (96 ... 1536) at batch 2."""
     from oracle import ref_model as RM
     from tests.common import oracle_trainer, hip_model_like, dev_draws
-    tr = oracle_trainer(64, 16, 64, 4)
-    gan = hip_model_like(tr)
-    batch = RM.synthetic_batch(tr.cfg, 29, 4)
+    tr = oracle_trainer(img, ch, 64, B)
+    gan = hip_model_like(tr, precision=mode)
+    assert gan.precision == mode
+    batch = RM.synthetic_batch(tr.cfg, 29, B)
     ro = tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], apply=False)
     ho = gan.d_step(cu(batch["real"]), cu(batch["z_d"]), dev_draws(batch["aug_real"]), dev_draws(batch["aug_fake_d"]),
                     apply=False)
     assert abs(ho["d_loss"].item() - ro["d_loss"].item()) <= 2e-2 * abs(ro["d_loss"].item())
     assert rel_err(t2n(ho["fake"]), ro["fake"].detach().numpy()) < 2e-2
-    k = "discriminator/resblock_down_4/res2/conv_0/kernel"
-    assert rel_err(t2n(gan.store.vars[k].bg_grad), ro["grads"][k].numpy()) < 5e-2
+    worst = _check_grads(gan, ro["grads"])
+    rg = tr.g_step(batch["z_g"], batch["aug_fake_g"], apply=False)
+    hg = gan.g_step(B, cu(batch["z_g"]), dev_draws(batch["aug_fake_g"]), apply=False)
+    assert abs(hg["g_loss"].item() - rg["g_loss"].item()) <= 2e-2 * abs(rg["g_loss"].item())
+    worst = max(worst, _check_grads(gan, rg["grads"]))
+    print("bf16 step parity [%s %d^2 ch%d]: worst gradient tensor rel. L2 = %.3e" % (mode, img, ch, worst))
+    from biggan_tensorflow_amd import functional as Fn
+    Fn.set_precision("fp32")
+
+
+def _check_grads(gan, ref_grads, tol=1e-1):
+    worst = 0.0
+    for k, g in ref_grads.items():
+        if k.endswith("self_attention/f_conv/bias") or k.endswith("self_attention/gamma"):
+            continue
+        gr = g.numpy()
+        if np.linalg.norm(gr) < 1e-12:
+            continue
+        e = rel_err(t2n(gan.store.vars[k].bg_grad), gr)
+        worst = max(worst, e)
+        assert e < tol, (k, e)
+    return worst

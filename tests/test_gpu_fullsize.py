@@ -43,7 +43,7 @@ def test_adjoint_identities_full_size(kind, N, H, Cin, Cout, k, s, mode):
     |y||g| in fp32 (fp32 accumulation over up to 9216-long reductions), 2e-2 in bf16-compute mode."""
     Fn, hip = _mods()
     L = hip.lib()
-    L.bg_set_gemm_compute(1 if mode == "bf16" else 0)
+    Fn.set_precision("bf16-staged" if mode == "bf16" else "fp32")
     try:
         x = _rnd((N, H, H, Cin), 1).requires_grad_(True)
         if kind == "conv":
@@ -63,7 +63,7 @@ def test_adjoint_identities_full_size(kind, N, H, Cin, Cout, k, s, mode):
         assert abs(lhs - _dot(w.detach(), w.grad)) <= tol, (lhs, _dot(w.detach(), w.grad), scale)
         assert torch.isfinite(y).all()
     finally:
-        L.bg_set_gemm_compute(0)
+        Fn.set_precision("fp32")
 
 
 def test_fused_attention_properties_full_size():

@@ -36,7 +36,7 @@ def cu(a, grad=False):
 def test_library_loaded_and_arch():
     hip = _hip()
     L = hip.lib()
-    assert L.bg_abi_version() == 1
+    assert L.bg_abi_version() == hip.ABI_VERSION
     assert L.bg_target_arch() == b"gfx950"
     with pytest.raises(RuntimeError):
         hip.f32(torch.zeros(4))          # CPU tensor: no fallback
