@@ -29,13 +29,15 @@ WORKLOADS = {
     "c2": (128, 64, 64, "BigGAN-128 ch=64 batch=64/GPU fp32 (BASELINE config 2)"),
     "c1": (64, 32, 16, "plumbing: BigGAN-64 ch=32 batch=16 fp32 (BASELINE config 1)"),
     "c3fp32": (128, 96, 32, "BigGAN-128 ch=96 batch=32/GPU fp32 (config 3 shape, fp32 kernels)"),
-    # bf16-compute conv / transposed-conv GEMMs (operands rounded to bf16 in LDS, fp32 accumulate, fp32 HBM tensors)
-    "c3": (128, 96, 32, "BigGAN-128 ch=96 batch=32/GPU (256 over 8 GPUs) bf16 conv compute (BASELINE config 3)"),
-    "c2bf16": (128, 64, 64, "BigGAN-128 ch=64 batch=64/GPU bf16 conv compute (config 2 shape)"),
-    "c4": (256, 96, 32, "BigGAN-256 ch=96 batch=32/GPU (256 over 8 GPUs) bf16 conv compute + DiffAugment (BASELINE config 4)"),
-    "c5": (512, 128, 64, "BigGAN-512 ch=128 batch=64/GPU (512 over 8 GPUs) bf16 conv compute (BASELINE config 5)"),
+    # bf16: bf16-resident activations + packed bf16 weights, fp32 accumulate / master weights / optimiser (--precision bf16)
+    "c3": (128, 96, 32, "BigGAN-128 ch=96 batch=32/GPU (256 over 8 GPUs) bf16 (BASELINE config 3)"),
+    "c2bf16": (128, 64, 64, "BigGAN-128 ch=64 batch=64/GPU bf16 (config 2 shape)"),
+    "c4": (256, 96, 32, "BigGAN-256 ch=96 batch=32/GPU (256 over 8 GPUs) bf16 + DiffAugment (BASELINE config 4)"),
+    "c5": (512, 128, 64, "BigGAN-512 ch=128 batch=64/GPU (512 over 8 GPUs) bf16 (BASELINE config 5)"),
+    # round-1 arithmetic for comparison: fp32 tensors, operands rounded to bf16 while staged (--precision bf16-staged)
+    "c3staged": (128, 96, 32, "BigGAN-128 ch=96 batch=32/GPU, fp32 tensors with bf16-staged conv operands"),
 }
-BF16_WORKLOADS = ("c3", "c2bf16", "c4", "c5")
+BF16_WORKLOADS = ("c3", "c2bf16", "c4", "c5", "c3staged")
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2516.6     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
@@ -163,6 +165,7 @@ def main():
     ap.add_argument("--n_labels", type=int, default=0, help="class-conditional variant: synthetic one-hot labels")
     ap.add_argument("--gan_type", type=str, default="hinge",
                     help="BASELINE's configs use hinge; e.g. ra-dragan (the reference's default) adds the gradient penalty")
+    ap.add_argument("--precision", type=str, default="", help="override: fp32 | bf16-staged | bf16")
     ap.add_argument("--graph", action="store_true", help="replay the iteration from captured HIP graphs (N=1 only)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
@@ -186,9 +189,10 @@ def main():
         B = a.batch
     argv = ["--gan_type", a.gan_type, "--img_size", str(img), "--ch", str(ch), "--batch_size", str(B),
             "--da_policy", a.da_policy, "--g_regularization", a.g_regularization, "--n_labels", str(a.n_labels)]
-    args = M.parse_args(argv, make_dirs=False)
     bf16 = a.workload in BF16_WORKLOADS
-    hip.lib().bg_set_gemm_compute(2 if bf16 else 0)     # 2: convs + the large regulariser GEMMs
+    precision = a.precision or ("bf16-staged" if a.workload == "c3staged" else "bf16" if bf16 else "fp32")
+    argv += ["--precision", precision]
+    args = M.parse_args(argv, make_dirs=False)
     peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
     gan = model.BigGAN(args, device="cuda", store=S.VariableStore("cuda", seed=42)).build_model()
     real = gan.synthetic_batch(B)
@@ -245,8 +249,8 @@ def main():
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                 "traffic_source": traffic_src,
-                "kernel": ("bg::nn_kernel_bf16 / bg::tn_kernel_bf16 (bf16 MFMA implicit GEMM: conv, deconv) + "
-                           "fp32 bg::nn_kernel for dense / attention / 1x1 launches that stay fp32") if bf16 else
+                "kernel": ("bg::nn16_kernel / bg::tn16_kernel (bf16-resident MFMA implicit GEMM: conv, deconv) + "
+                           "the fp32-tensor kernels for the image layers, dense layers and attention") if bf16 else
                           "bg::nn_kernel / bg::tn_kernel (fp32 MFMA implicit GEMM: conv, deconv, dense) + bg::attn_* (fused attention)",
                 "launches_per_step": int(n.value // nprof), "gemm_ms_per_step": round(ms.value / nprof, 3),
                 "gemm_flops_per_step": fl.value / nprof,
@@ -267,7 +271,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": desc, "img_size": img, "ch": ch, "per_gpu_batch": B, "global_batch": B * world,
-                       "da_policy": a.da_policy, "g_regularization": a.g_regularization, "n_labels": a.n_labels, "gan_type": a.gan_type, "hip_graph": bool(a.graph),
+                       "da_policy": a.da_policy, "g_regularization": a.g_regularization, "n_labels": a.n_labels, "gan_type": a.gan_type, "hip_graph": bool(a.graph), "precision": precision,
                        "parallelism": "dp%d" % world},
             "losses": {k: round(float(v.item()), 5) for k, v in losses.items()},
         }

@@ -5,7 +5,8 @@ from biggan_tensorflow_amd import main as M, model, scope as S, ops, hip
 img, ch, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 out = sys.argv[4]
 import os
-if os.environ.get("BF16"): hip.lib().bg_set_gemm_compute(1)
+if os.environ.get("BF16"):
+    from biggan_tensorflow_amd import functional as Fn; Fn.set_precision("bf16-staged")
 args = M.parse_args(["--gan_type","hinge","--img_size",str(img),"--ch",str(ch),"--batch_size",str(B)] + sys.argv[5:], make_dirs=False)
 gan = model.BigGAN(args, store=S.VariableStore("cuda")).build_model()
 real = gan.synthetic_batch(B)

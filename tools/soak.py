@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import biggan_tensorflow_amd
 from biggan_tensorflow_amd import main as M, model, scope as S, hip
 mode = int(sys.argv[1]); iters = int(sys.argv[2])
-hip.lib().bg_set_gemm_compute(mode)
+from biggan_tensorflow_amd import functional as Fn; Fn.set_precision({0: "fp32", 1: "bf16-staged", 2: "bf16-staged", 3: "bf16"}[mode])
 args = M.parse_args(["--gan_type", "hinge", "--img_size", "64", "--ch", "32", "--batch_size", "16"] + sys.argv[3:], make_dirs=False)
 gan = model.BigGAN(args, store=S.VariableStore("cuda")).build_model()
 real = gan.synthetic_batch(16)
