@@ -1173,8 +1173,8 @@ __global__ __launch_bounds__(EW_BLOCK) void dot_t_kernel(const T* __restrict__ a
 // of one tap through LDS so that both copies are written in 128-byte row segments
 __device__ __forceinline__ void sn_normalize_pack_body(const float* __restrict__ w, float sigma,
                                                        float* __restrict__ wn, __bf16* __restrict__ pp,
-                                                       __bf16* __restrict__ pt, int taps, int R, int Cc, int bid,
-                                                       int nblocks, float (*tile)[65]) {
+                                                       __bf16* __restrict__ pt, int taps, int R, int Cc, int pld,
+                                                       int bid, int nblocks, float (*tile)[65]) {
     const int tr = (R + 63) / 64, tc = (Cc + 63) / 64;
     const int ntiles = taps * tr * tc;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 element pairs x 8 rows per pass
@@ -1193,7 +1193,7 @@ __device__ __forceinline__ void sn_normalize_pack_body(const float* __restrict__
                 v0 = wv.x / sigma;
                 v1 = wv.y / sigma;
                 if (wn) *reinterpret_cast<float2*>(wn + base + (int64_t)r * Cc + c) = make_float2(v0, v1);
-                *reinterpret_cast<uint32_t*>(pp + base + (int64_t)r * Cc + c) = bf16_pack2(v0, v1);
+                *reinterpret_cast<uint32_t*>(pp + (int64_t)tap * R * pld + (int64_t)r * pld + c) = bf16_pack2(v0, v1);
             }
             tile[ty + 8 * ps][2 * tx] = v0;
             tile[ty + 8 * ps][2 * tx + 1] = v1;
@@ -1212,7 +1212,7 @@ __device__ __forceinline__ void sn_normalize_pack_body(const float* __restrict__
 __global__ __launch_bounds__(EW_BLOCK) void weight_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ pp,
                                                                 __bf16* __restrict__ pt, int taps, int R, int Cc) {
     __shared__ float tile[64][65];
-    sn_normalize_pack_body(w, 1.0f, nullptr, pp, pt, taps, R, Cc, blockIdx.x, gridDim.x, tile);
+    sn_normalize_pack_body(w, 1.0f, nullptr, pp, pt, taps, R, Cc, Cc, blockIdx.x, gridDim.x, tile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1424,8 +1424,8 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_batch_normalize_kernel(const BgSn
     if (it.pack_p) {
         // conv / transposed-conv kernel of the bf16-resident path: w / sigma in fp32 plus the two bf16 packed copies
         sn_normalize_pack_body(it.w, (float)scr[1], it.w_norm, reinterpret_cast<__bf16*>(it.pack_p),
-                               reinterpret_cast<__bf16*>(it.pack_t), it.taps, it.rows / it.taps, it.cols, blockIdx.x,
-                               gridDim.x, tile);
+                               reinterpret_cast<__bf16*>(it.pack_t), it.taps, it.rows / it.taps, it.cols,
+                               it.pack_p_ld > 0 ? it.pack_p_ld : it.cols, blockIdx.x, gridDim.x, tile);
         const float rs_v = (float)scr[2];
         for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < it.rows; i += (int64_t)gridDim.x * EW_BLOCK)
             it.v[i] = vraw[i] * rs_v;

@@ -28,6 +28,8 @@ struct NN16Params {
     int64_t slab_stride;
     int32_t tiles_m, tiles_n;
     int32_t zfold;
+    int32_t pow2;           // g.Wq and g.Hq are powers of two: row -> (b, hq, wq) by shifts instead of divisions
+    int32_t wq_shift, hq_shift;
 };
 
 struct TN16Params {

@@ -67,6 +67,38 @@ constexpr int nn16_lds_bytes(int TN) {
     return 2 * stage > epi ? 2 * stage : epi;
 }
 
+// element offset of the source pixel of row r under tap (kh, kw), or -1 (selects, no divergent branches)
+template <int MODE>
+__device__ __forceinline__ int64_t nn16_src_off(const Gather& g, const RowPos& r, int kh, int kw) {
+    int h, w;
+    if (MODE == GATHER_CONV) {
+        h = conv_src(r.ho, kh, g.stride, g.pad, g.reflect, g.Hs);
+        w = conv_src(r.wo, kw, g.stride, g.pad, g.reflect, g.Ws);
+    } else {
+        h = tconv_src_from_num(r.ho + g.pad - kh, g.stride, g.Hs);
+        w = tconv_src_from_num(r.wo + g.pad - kw, g.stride, g.Ws);
+    }
+    const bool ok = r.valid && h >= 0 && w >= 0;
+    const int pix = (r.b * g.Hs + h) * g.Ws + w;          // < 2^31 (checked on the host)
+    return ok ? (int64_t)pix * g.ld : (int64_t)-1;
+}
+
+// row of the implicit GEMM -> output pixel of this stride phase (shifts when the phase grid is a power of two: the
+// divisions of decompose_row cost ~90 VALU instructions per row, as much as several K steps of a C = 96 layer)
+template <int MODE>
+__device__ __forceinline__ RowPos nn16_row(const NN16Params& p, int m, int ph, int pw) {
+    if (MODE == GATHER_PLAIN || !p.pow2) return decompose_row<MODE>(p.g, m, p.M, ph, pw);
+    RowPos r;
+    r.valid = m < p.M;
+    const int wq = m & (p.g.Wq - 1);
+    const int t = m >> p.wq_shift;
+    const int hq = t & (p.g.Hq - 1);
+    r.b = t >> p.hq_shift;
+    r.ho = hq * p.g.pstep + ph;
+    r.wo = wq * p.g.pstep + pw;
+    return r;
+}
+
 template <int TN, int MODE>
 __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
     constexpr int BM = NN16_BM, BN = 32 * TN;
@@ -116,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
     const int rsub = 8 * w + (lane >> 3);
     RowPos rows[JA];
 #pragma unroll
-    for (int j = 0; j < JA; ++j) rows[j] = decompose_row<MODE>(g, m0 + 32 * j + rsub, p.M, ph, pw);
+    for (int j = 0; j < JA; ++j) rows[j] = nn16_row<MODE>(p, m0 + 32 * j + rsub, ph, pw);
     const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
     const __bf16* Bb = reinterpret_cast<const __bf16*>(p.B);
     const void* zero = reinterpret_cast<const void*>(g_zero_page);
@@ -134,11 +166,7 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
             const int ih = tidx / nkw, iw = tidx - ih * nkw;
             const int kh = kh0 + ih * kstep, kw = kw0 + iw * kstep;
 #pragma unroll
-            for (int j = 0; j < JA; ++j) {
-                int64_t off[1];
-                tap_sources<MODE, false>(g, rows[j], kh, kw, off);
-                aoff[j] = off[0];
-            }
+            for (int j = 0; j < JA; ++j) aoff[j] = nn16_src_off<MODE>(g, rows[j], kh, kw);
             wtap = Bb + (int64_t)(kh * g.k + kw) * p.tap_stride;
         } else {
 #pragma unroll
@@ -195,22 +223,25 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
         const int cur = it & 1;
         if (it + 1 < nsteps) stage(cur ^ 1);
         const unsigned char* sbuf = smem + cur * STAGE;
+        // all operand reads of the K step are issued up front (the second half lands behind the first half's MFMAs)
+        bf16x8_t a[2][4], b[2][TN];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8_t a[4], b[TN];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                a[i] = *reinterpret_cast<const bf16x8_t*>(sbuf + a_row + i * 16 * 128 + koff[s2]);
+                a[s2][i] = *reinterpret_cast<const bf16x8_t*>(sbuf + a_row + i * 16 * 128 + koff[s2]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const bf16x8_t*>(sbuf + b_row + j * 16 * 128 + koff[s2]);
-            // weights as the MFMA's first operand: D rows = output channels (4 per lane), D columns = pixels
+                b[s2][j] = *reinterpret_cast<const bf16x8_t*>(sbuf + b_row + j * 16 * 128 + koff[s2]);
+        }
+        // weights as the MFMA's first operand: D rows = output channels (4 per lane), D columns = pixels
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[s2][j], a[s2][i], acc[i][j], 0, 0, 0);
         __syncthreads();
     }
 
@@ -240,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
         if (m >= p.M || col >= p.N) continue;
         int64_t ooff;
         if (MODE == GATHER_TCONV) {
-            const RowPos rp = decompose_row<MODE>(g, m, p.M, ph, pw);
+            const RowPos rp = nn16_row<MODE>(p, m, ph, pw);
             if (rp.ho >= g.Ho || rp.wo >= g.Wo) continue;
             ooff = (((int64_t)rp.b * g.Ho + rp.ho) * g.Wo + rp.wo) * p.out_ld + col;
         } else {
@@ -353,10 +384,15 @@ __global__ __launch_bounds__(256, 2) void tn16_kernel(const TN16Params p) {
     const int wm = w >> 1, wn = w & 1;
     const Gather& g = p.g;
 
-    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    // split-major logical order inside each XCD: the (M, N) tiles of one pixel range run together on ONE XCD, so the
+    // x / dy rows of that range are fetched into that L2 once and shared (the kernel is otherwise bound by L2 misses:
+    // every tile streams the whole pixel range)
+    const int ntile = p.tiles_m * p.tiles_n;
+    const int lin = xcd_remap(blockIdx.x, ntile * p.splitk);
+    const int zs = lin / ntile;
+    const int tile = lin - zs * ntile;
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
     const int mf0 = tile_m * BM, cb0 = tile_n * BN;
-    const int zs = blockIdx.z;
     const int row_begin = zs * p.rows_per_split;
     const int row_end = min(p.M, row_begin + p.rows_per_split);
     const int nsteps = max(0, (row_end - row_begin + TN16_BK - 1) / TN16_BK);
@@ -588,30 +624,31 @@ static int nn16_steps_min(const NN16Params& p, int mode) {
     return (per_axis * per_axis * (p.C >> 3) + 7) >> 3;
 }
 
+// Tile width and split-K by a round model: the grid runs in rounds of `slots` co-resident blocks (2 per CU); a block's
+// time is its K steps x (A-side work + one unit per 32 output columns).  Fewer, wider tiles waste padded columns and
+// can leave the last round (or the only one) mostly empty; narrow ones re-read the A tile more often.
 static NN16Plan plan_nn16(const NN16Params& p, int mode, int zdim, bool allow_split) {
-    NN16Plan pl;
-    // N tile: the width in {128, 96, 64, 32} that wastes the fewest padded columns (ties: the wider one)
-    int best = 4, best_waste = 1 << 30;
+    static const int slots = getenv("BG_NN16_SLOTS") ? atoi(getenv("BG_NN16_SLOTS")) : 512;
+    const int64_t tm = (p.M + NN16_BM - 1) / NN16_BM;
+    const int steps = nn16_steps_min(p, mode);
+    NN16Plan best{4, 1};
+    double best_cost = 1e30;
     for (int tn = 4; tn >= 1; --tn) {
         const int bn = 32 * tn;
-        const int waste = (p.N + bn - 1) / bn * bn - p.N;
-        if (waste < best_waste) {
-            best_waste = waste;
-            best = tn;
+        const int64_t tiles = tm * ((p.N + bn - 1) / bn) * zdim;
+        const double unit = 1.5 + tn;
+        const int max_sk = allow_split ? (steps / 4 < 16 ? (steps / 4 < 1 ? 1 : steps / 4) : 16) : 1;
+        for (int sk = 1; sk <= max_sk; ++sk) {
+            const int64_t rounds = (tiles * sk + slots - 1) / slots;
+            double cost = (double)rounds * ((steps + sk - 1) / sk + 2.0) * unit;     // + prologue / epilogue per block
+            if (sk > 1) cost += 6.0 * unit + 0.02 * sk * (double)tiles / slots * bn; // reduce launch + slab traffic
+            if (cost < best_cost - 1e-9) {
+                best_cost = cost;
+                best = NN16Plan{tn, sk};
+            }
         }
     }
-    pl.tn = best;
-    pl.splitk = 1;
-    const int64_t tiles = (int64_t)((p.M + NN16_BM - 1) / NN16_BM) * ((p.N + 32 * pl.tn - 1) / (32 * pl.tn)) * zdim;
-    const int steps = nn16_steps_min(p, mode);
-    static const int want = getenv("BG_NN16_WANT") ? atoi(getenv("BG_NN16_WANT")) : 512;   // 2 blocks per CU
-    if (allow_split && tiles < want && steps >= 8) {
-        int sk = (int)((want + tiles - 1) / tiles);
-        if (sk > steps / 4) sk = steps / 4;
-        if (sk > 16) sk = 16;
-        if (sk > 1) pl.splitk = sk;
-    }
-    return pl;
+    return best;
 }
 
 size_t nn16_workspace_bytes(const NN16Params& p, int mode, int zdim, int64_t out_elems) {
@@ -660,6 +697,12 @@ int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, 
     const int bn = 32 * pl.tn;
     p.tiles_m = (p.M + NN16_BM - 1) / NN16_BM;
     p.tiles_n = (p.N + bn - 1) / bn;
+    p.pow2 = 0;
+    if (p.g.Wq > 0 && p.g.Hq > 0 && (p.g.Wq & (p.g.Wq - 1)) == 0 && (p.g.Hq & (p.g.Hq - 1)) == 0) {
+        p.pow2 = 1;
+        p.wq_shift = __builtin_ctz(p.g.Wq);
+        p.hq_shift = __builtin_ctz(p.g.Hq);
+    }
     dim3 grid(p.tiles_m * p.tiles_n, 1, zdim * p.splitk);
     p.zfold = 0;
     if (mode == GATHER_TCONV && zdim > 1 && p.splitk == 1 && p.g.k % p.g.stride == 0) {
@@ -687,7 +730,7 @@ int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, 
 static void plan_tn16(TN16Params& p) {
     const int64_t tiles = (int64_t)((p.Mf + 127) / 128) * ((p.Cb + 127) / 128);
     static const int want = getenv("BG_TN16_WANT") ? atoi(getenv("BG_TN16_WANT")) : 1024;
-    int sk = (int)((want + tiles - 1) / tiles);
+    int sk = (int)(want / tiles);          // (floor: tiles * sk <= want = a whole number of rounds of 512 co-resident blocks)
     const int max_sk = (p.M + 4 * TN16_BK - 1) / (4 * TN16_BK);      // at least 256 pixels per split
     if (sk > max_sk) sk = max_sk;
     if (sk < 1) sk = 1;
@@ -730,7 +773,7 @@ int launch_tn16(TN16Params& p, int mode, float* final_out, void* ws, size_t ws_b
         p.wq_shift = __builtin_ctz(p.g.Wq);
         p.hq_shift = __builtin_ctz(p.g.Hq);
     }
-    dim3 grid(p.tiles_m * p.tiles_n, 1, p.splitk);
+    dim3 grid(p.tiles_m * p.tiles_n * p.splitk, 1, 1);
     constexpr int lds = 4 * TN16_TILE;
     static bool attr_done = false;
     if (!attr_done) {

@@ -448,6 +448,112 @@ class AttentionFn(Function):
         return dqq, dkk, dvv
 
 
+class SaFrontFn(Function):
+    """bf16-resident front half of self_attention_2 (ops.py:467-485): the f | g | h 1x1 projections as ONE GEMM on the
+    shared packed weights, one 2x2 max pool of the result, and the fused bf16 attention reading q = g, k = pool(f),
+    v = pool(h) as column slices (csrc/attention16.hip).  x [B,H,W,C] bf16 -> o [B,H,W,c_h] bf16."""
+
+    @staticmethod
+    def supported(x, wf, wg, wh):
+        grp = getattr(wf, "bg_group", None)
+        if grp is None or getattr(wg, "bg_group", None) is not grp or getattr(wh, "bg_group", None) is not grp:
+            return False
+        if x.dtype != BF16 or x.dim() != 4 or x.shape[1] % 2 or x.shape[2] % 2:
+            return False
+        N, Nk = x.shape[1] * x.shape[2], x.shape[1] * x.shape[2] // 4
+        return bool(lib().bg_attention16_supported(N, Nk, wf.shape[3], wh.shape[3])) and wf.shape[3] == wg.shape[3]
+
+    @staticmethod
+    def _desc(B, N, Nk, d, dv, ct):
+        D = hip.BgAttn16Desc()
+        D.B, D.N, D.Nk, D.d, D.dv = B, N, Nk, d, dv
+        D.ldq, D.sq, D.ldk, D.sk, D.ldv, D.sv = ct, N * ct, ct, Nk * ct, ct, Nk * ct
+        D.ldo, D.so, D.ldg, D.sg = dv, N * dv, dv, N * dv
+        D.lddq, D.sdq, D.lddk, D.sdk, D.lddv, D.sdv = ct, N * ct, ct, Nk * ct, ct, Nk * ct
+        return D
+
+    @staticmethod
+    def forward(ctx, x, wf, wg, wh, bf_, bg_, bh_):
+        x = _c(x)
+        B, H, W_, C = x.shape
+        grp = wf.bg_group
+        ct = grp.pack_p.shape[2]
+        of, og, oh = wf.bg_group_off, wg.bg_group_off, wh.bg_group_off
+        d, dv = wf.shape[3], wh.shape[3]
+        L = lib()
+        bias = None
+        if bf_ is not None:
+            bias = torch.empty(ct, dtype=torch.float32, device=x.device)
+            with torch.no_grad():
+                for o_, b_ in ((of, bf_), (og, bg_), (oh, bh_)):
+                    bias[o_:o_ + b_.shape[0]].copy_(b_)                   # (device-to-device copies of 3 small vectors)
+        cd = hip.conv_desc(B, H, W_, C, H, W_, ct, 1, 1, 0, hip.PAD_REFLECT, hip.COMPUTE_BF16, hip.BF16, hip.BF16, 1)
+        y = torch.empty((B, H, W_, ct), dtype=BF16, device=x.device)
+        ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, cd, x.device)
+        check(L.bg_conv2d_fwd(cd, act(x), act(grp.pack_t), f32(bias), None, act(y), 0, f32(ws), nb, stream()))
+        yp = torch.empty((B, H // 2, W_ // 2, ct), dtype=BF16, device=x.device)
+        check(L.bg_maxpool2_fwd_t(act(y), act(yp), hip.BF16, B, H, W_, ct, stream()))
+        N, Nk = H * W_, (H // 2) * (W_ // 2)
+        o = torch.empty((B, H, W_, dv), dtype=BF16, device=x.device)
+        lse = torch.empty((B, N), dtype=torch.float32, device=x.device)
+        D = SaFrontFn._desc(B, N, Nk, d, dv, ct)
+        P = hip.c_void_p
+        check(L.bg_attention16_fwd(D, P(y.data_ptr() + 2 * og), P(yp.data_ptr() + 2 * of), P(yp.data_ptr() + 2 * oh),
+                                   act(o), f32(lse), stream()))
+        ctx.saved = (x, y, yp, o, lse)
+        ctx.vars = (wf, wg, wh, bf_, bg_, bh_)
+        ctx.cd, ctx.D, ctx.offs = cd, D, (of, og, oh)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        do = cast(_c(do), BF16)
+        x, y, yp, o, lse = ctx.saved
+        wf, wg, wh, bf_, bg_, bh_ = ctx.vars
+        of, og, oh = ctx.offs
+        cd, D = ctx.cd, ctx.D
+        grp = wf.bg_group
+        ct = grp.pack_p.shape[2]
+        B, H, W_, C = x.shape
+        L = lib()
+        P = hip.c_void_p
+        dev = x.device
+        # gradients of the pooled keys / values (the query columns of the pooled tensor receive nothing)
+        dyp = torch.zeros_like(yp)
+        delta = torch.empty((B, D.N), dtype=torch.float32, device=dev)
+        qp, kp, vp = P(y.data_ptr() + 2 * og), P(yp.data_ptr() + 2 * of), P(yp.data_ptr() + 2 * oh)
+        check(L.bg_attention16_bwd(D, qp, kp, vp, act(o), act(do), f32(lse), None, P(dyp.data_ptr() + 2 * of),
+                                   P(dyp.data_ptr() + 2 * oh), f32(delta), stream()))
+        dy = torch.empty_like(y)
+        check(L.bg_maxpool2_bwd_t(act(y), act(dyp), act(dy), hip.BF16, B, H, W_, ct, stream()))
+        # ... then the query gradient goes straight into its (so far zero) columns of dy
+        check(L.bg_attention16_bwd(D, qp, kp, vp, act(o), act(do), f32(lse), P(dy.data_ptr() + 2 * og), None, None,
+                                   f32(delta), stream()))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ws, nb = hip.scratch(L.bg_conv2d_dgrad_workspace_bytes, cd, dev)
+            check(L.bg_conv2d_dgrad(cd, act(dy), act(grp.pack_p), None, act(dx), 0, f32(ws), nb, stream()))
+        if not _Mode.inputs_only:
+            need_w = any(w.requires_grad for w in (wf, wg, wh))
+            if need_w:
+                dwt = torch.empty((C, ct), dtype=torch.float32, device=dev)
+                nb = L.bg_conv2d_wgrad_workspace_bytes(cd)
+                ws = workspace(nb, dev)
+                check(L.bg_conv2d_wgrad(cd, act(x), act(dy), f32(dwt), f32(ws), nb, stream()))
+                for w_, o_ in ((wf, of), (wg, og), (wh, oh)):
+                    if w_.requires_grad:
+                        emit_grad(w_, lambda out, o_=o_, w_=w_: out.view(C, w_.shape[3]).copy_(dwt[:, o_:o_ + w_.shape[3]]))
+            if bf_ is not None and any(b_.requires_grad for b_ in (bf_, bg_, bh_)):
+                dbt = torch.empty(ct, dtype=torch.float32, device=dev)
+                _bias_grad(dy.view(-1, ct), dbt)
+                for b_, o_ in ((bf_, of), (bg_, og), (bh_, oh)):
+                    if b_.requires_grad:
+                        emit_grad(b_, lambda out, o_=o_, b_=b_: out.copy_(dbt[o_:o_ + b_.shape[0]]))
+        ctx.saved = None
+        return dx, None, None, None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------
 # spectral norm
 # ------------------------------------------------------------------------------------------
@@ -488,6 +594,13 @@ class SpectralNormFn(Function):
         return dw, None
 
 
+class PackGroup:
+    """Shared packed bf16 copies of several 1x1 kernels on one input: pack_p [1, C, ct], pack_t [1, ct, C]."""
+
+    def __init__(self, pack_p, pack_t):
+        self.pack_p, self.pack_t, self.offsets = pack_p, pack_t, []
+
+
 class SnBatch:
     """Every spectrally-normalised weight of one network in one multi-tensor call (4 launches forward,
     2 backward) instead of a kernel chain per weight.  ``forward()`` runs the power iteration of all
@@ -497,7 +610,10 @@ class SnBatch:
 
     ALIGN = 64
 
-    def __init__(self, pairs):
+    def __init__(self, pairs, groups=None):
+        """``groups`` (bf16-resident mode): lists of indices into ``pairs`` of 1x1 kernels [1,1,C,c_i] applied to the
+        same tensor (the f | g | h projections of self_attention_2): their packed copies are slices of one shared
+        [C, sum c_i] / [sum c_i, C] pair, so the three projections are ONE GEMM in each direction."""
         import ctypes
         L = lib()
         self.w = [p[0] for p in pairs]
@@ -524,6 +640,21 @@ class SnBatch:
         # also gets its two packed bf16 copies, written by the same normalisation launch
         packed = [Precision.resident and w.dim() == 4 and w.shape[2] % 8 == 0 and w.shape[3] % 8 == 0 for w in self.w]
         self.pack_flat = torch.zeros(2 * off if any(packed) else 0, dtype=BF16, device=dev)
+        group_of = {}
+        for gi, members in enumerate(groups or []):
+            ws_ = [self.w[i] for i in members]
+            cin = ws_[0].shape[2]
+            if not (Precision.resident and all(w.dim() == 4 and w.shape[0] == 1 and w.shape[1] == 1 and w.shape[2] == cin
+                                                and w.shape[3] % 4 == 0 for w in ws_) and cin % 8 == 0
+                    and sum(w.shape[3] for w in ws_) % 8 == 0):
+                continue
+            ct = sum(w.shape[3] for w in ws_)
+            grp = PackGroup(torch.zeros((1, cin, ct), dtype=BF16, device=dev), torch.zeros((1, ct, cin), dtype=BF16, device=dev))
+            o = 0
+            for i in members:
+                group_of[i] = (grp, o)
+                grp.offsets.append(o)
+                o += self.w[i].shape[3]
         self.v_flat = torch.zeros(rows_tot, dtype=torch.float32, device=dev)
         self.sigma = torch.zeros(n, dtype=torch.float32, device=dev)
         self.ws_bytes = ws_off
@@ -552,7 +683,13 @@ class SnBatch:
             it.sigma = self.sigma.data_ptr() + 4 * i
             it.w_norm, it.g_wnorm, it.dw = wn.data_ptr(), wn.bg_grad.data_ptr(), dw.data_ptr()
             it.ws_offset, it.rows, it.cols = ws_offs[i], self.rows[i], self.cols[i]
-            if packed[i]:
+            if i in group_of:
+                grp, o = group_of[i]
+                wn.bg_group, wn.bg_group_off = grp, o
+                it.pack_p = grp.pack_p.data_ptr() + 2 * o                      # column slice of [C, ct]
+                it.pack_t = grp.pack_t.data_ptr() + 2 * o * w.shape[2]         # row block of [ct, C]
+                it.taps, it.pack_p_ld = 1, grp.pack_p.shape[2]
+            elif packed[i]:
                 k2, A, B = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
                 wn.bg_pack_p = self.pack_flat.narrow(0, 2 * offs[i], w.numel()).view(k2, A, B)
                 wn.bg_pack_t = self.pack_flat.narrow(0, 2 * offs[i] + w.numel(), w.numel()).view(k2, B, A)

@@ -36,10 +36,17 @@ class BgGemmDesc(Structure):
 class BgSnItem(Structure):
     _fields_ = [("w", c_void_p), ("u", c_void_p), ("v", c_void_p), ("sigma", c_void_p), ("w_norm", c_void_p),
                 ("g_wnorm", c_void_p), ("dw", c_void_p), ("ws_offset", c_int64), ("rows", c_int32), ("cols", c_int32),
-                ("pack_p", c_void_p), ("pack_t", c_void_p), ("taps", c_int32), ("reserved", c_int32)]
+                ("pack_p", c_void_p), ("pack_t", c_void_p), ("taps", c_int32), ("pack_p_ld", c_int32)]
+
+
+class BgAttn16Desc(Structure):
+    _fields_ = [(n, c_int32) for n in ("B", "N", "Nk", "d", "dv", "reserved")] + \
+               [(n, c_int64) for n in ("ldq", "sq", "ldk", "sk", "ldv", "sv", "ldo", "so",
+                                       "ldg", "sg", "lddq", "sdq", "lddk", "sdk", "lddv", "sdv")]
 
 
 _P = c_void_p
+_AD = POINTER(BgAttn16Desc)
 _CD = POINTER(BgConvDesc)
 _GD = POINTER(BgGemmDesc)
 
@@ -76,6 +83,9 @@ SIGNATURES = {
     "bg_attention2_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "bg_attention2_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bg_attention2_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bg_attention16_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "bg_attention16_fwd": (c_int, [_AD, _P, _P, _P, _P, _P, _P]),
+    "bg_attention16_bwd": (c_int, [_AD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "bg_spectral_norm_workspace_bytes": (c_size_t, [c_int, c_int]),
     "bg_spectral_norm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
     "bg_spectral_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),

@@ -423,8 +423,20 @@ class BigGAN(GANBase):
             for group in ("generator", "discriminator"):
                 pairs = [(self.store.vars[w], self.store.vars[u]) for w, u in self.store.sn_pairs.items()
                          if w.startswith(group + "/") and w in self.store.arenas[group].offsets]
+                names = [w for w, u in self.store.sn_pairs.items()
+                         if w.startswith(group + "/") and w in self.store.arenas[group].offsets]
                 for i in range(0, len(pairs), 256):
-                    self.sn_batches.setdefault(group, []).append(Fn.SnBatch(pairs[i:i + 256]))
+                    chunk = names[i:i + 256]
+                    # f | g | h projections of every self-attention block share one packed GEMM operand
+                    groups = []
+                    for j, nm in enumerate(chunk):
+                        if nm.endswith("/f_conv/kernel"):
+                            pre = nm[:-len("f_conv/kernel")]
+                            try:
+                                groups.append([j, chunk.index(pre + "g_conv/kernel"), chunk.index(pre + "h_conv/kernel")])
+                            except ValueError:
+                                pass
+                    self.sn_batches.setdefault(group, []).append(Fn.SnBatch(pairs[i:i + 256], groups))
         self.reg_owner = self._shard_regularisers()
         self.counter = 0
         self.built = True

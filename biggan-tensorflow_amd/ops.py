@@ -508,10 +508,36 @@ def self_attention(x, channels, opt, scope='self_attention'):
     raise NotImplementedError("self_attention (ops.py:445) is never called by the reference; use self_attention_2")
 
 
+def _conv1x1_vars(name, cin, cout, opt, use_bias):
+    """The variables conv(x, cout, kernel=1, stride=1, scope=name) creates, in its order, without running it."""
+    with variable_scope(name) as full_scope:
+        reg = opt.get("conv", {}).get("regularizer", None) if 'generator' in full_scope else None
+        w = get_variable("kernel", shape=[1, 1, cin, cout], initializer=weight_init, regularizer=reg)
+        _regularize(w, reg)
+        wk = spectral_norm(w) if opt.get("conv", {}).get("sn", True) else w
+        bias = get_variable("bias", [cout], initializer=S.constant_initializer(0.0)) if use_bias else None
+    return wk, bias
+
+
 def self_attention_2(x, channels, opt, scope='self_attention'):
     """ops.py:467-492."""
     with variable_scope(scope):
         use_bias = opt.get("self_attention_bias", False)
+        if (Fn.Precision.resident and not _is_meta(x) and not _is_dual(x) and x.dtype == torch.bfloat16
+                and channels % 8 == 0 and (channels // 2) % 8 == 0):
+            # bf16-resident: f | g | h as one GEMM, one pool, fused bf16 attention on column slices
+            C = x.shape[-1]
+            wf, b_f = _conv1x1_vars('f_conv', C, channels // 8, opt, use_bias)
+            wg, b_g = _conv1x1_vars('g_conv', C, channels // 8, opt, use_bias)
+            wh, b_h = _conv1x1_vars('h_conv', C, channels // 2, opt, use_bias)
+            if Fn.SaFrontFn.supported(x, wf, wg, wh):
+                x_qkv, x_res = _fork(x, 2)
+                gamma = get_variable("gamma", [1], initializer=S.constant_initializer(0.0))
+                o = Fn.SaFrontFn.apply(x_qkv, wf, wg, wh, b_f, b_g, b_h)
+                o = conv(o, channels, kernel=1, stride=1, opt=opt, scope='attn_conv', use_bias=use_bias)
+                return Fn.ScaleAddFn.apply(o, gamma, x_res)
+            # (narrow test models: d = channels // 8 is not a multiple of 4 -> the generic path below; the variables
+            #  above are the ones it uses, created once per scope)
         x_f, x_g, x_h, x = _fork(x, 4)
         # (bf16-resident mode: the attention core stays fp32 - its 1x1 producers write fp32 directly)
         f32o = None if _is_meta(x) or _is_dual(x) or x.dtype == torch.float32 else torch.float32

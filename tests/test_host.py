@@ -119,6 +119,14 @@ def test_abi_rejects_null_tensors_before_any_launch():
                 vals.append(dd if "deconv" in name else rd if "rgb" in name else td if "thin" in name else cd)
             elif a is hip._GD:
                 vals.append(gd)
+            elif a is hip._AD:
+                ad = hip.BgAttn16Desc()
+                ad.B, ad.N, ad.Nk, ad.d, ad.dv = 1, 128, 128, 16, 32
+                for f_ in ("ldq", "ldk", "lddq", "lddk"):
+                    setattr(ad, f_, 16)
+                for f_ in ("ldv", "ldo", "ldg", "lddv"):
+                    setattr(ad, f_, 32)
+                vals.append(ad)
             elif a is ctypes.c_void_p or a is ctypes.c_char_p:
                 vals.append(None)
             elif a in (ctypes.c_float, ctypes.c_double):
