@@ -73,3 +73,58 @@ def DiffAugment(x, policy='', channels_first=False, draws=None, generator=None):
         draws = draw(B, S, x.device, generator)
     d = draws
     return Fn.DiffAugmentFn.apply(x, d["u_b"], d["u_s"], d["u_c"], d["t_x"], d["t_y"], d["o_x"], d["o_y"], bits)
+
+
+# ------------------------------------------------------------------------------------------
+# The reference's per-transform names (DiffAugment_tf.py:20-73).  Each is the fused kernel restricted to one
+# transform, with its own draws (same distributions, same order) unless ``draws`` is given.
+# ------------------------------------------------------------------------------------------
+def _single(x, bits, draws=None, generator=None):
+    d = draws if draws is not None else draw(x.shape[0], x.shape[1], x.device, generator)
+    return Fn.DiffAugmentFn.apply(x, d["u_b"], d["u_s"], d["u_c"], d["t_x"], d["t_y"], d["o_x"], d["o_y"], bits)
+
+
+def _neutral_color(x, draws, generator, keep):
+    """Draws of a colour-only call in which every colour transform except ``keep`` is the identity
+    (brightness offset 0 at u_b = 0.5, saturation factor 1 at u_s = 0.5, contrast factor 1 at u_c = 0.5)."""
+    d = dict(draws if draws is not None else draw(x.shape[0], x.shape[1], x.device, generator))
+    for k in ("u_b", "u_s", "u_c"):
+        if k != keep:
+            d[k] = torch.full_like(d[k], 0.5)
+    return d
+
+
+def rand_brightness(x, draws=None, generator=None):
+    """DiffAugment_tf.py:20-23: x + (u - 0.5)."""
+    return _single(x, _BITS["color"], _neutral_color(x, draws, generator, "u_b"))
+
+
+def rand_saturation(x, draws=None, generator=None):
+    """DiffAugment_tf.py:26-30: (x - mean_C) * 2u + mean_C."""
+    return _single(x, _BITS["color"], _neutral_color(x, draws, generator, "u_s"))
+
+
+def rand_contrast(x, draws=None, generator=None):
+    """DiffAugment_tf.py:33-37: (x - mean_HWC) * (u + 0.5) + mean_HWC."""
+    return _single(x, _BITS["color"], _neutral_color(x, draws, generator, "u_c"))
+
+
+def rand_translation(x, ratio=0.125, draws=None, generator=None):
+    """DiffAugment_tf.py:40-50 (ratio is fixed at the reference's 0.125 inside the kernel)."""
+    if ratio != 0.125:
+        raise NotImplementedError("rand_translation ratio != 0.125")
+    return _single(x, _BITS["translation"], draws, generator)
+
+
+def rand_cutout(x, ratio=0.5, draws=None, generator=None):
+    """DiffAugment_tf.py:53-66 (ratio is fixed at the reference's 0.5 inside the kernel)."""
+    if ratio != 0.5:
+        raise NotImplementedError("rand_cutout ratio != 0.5")
+    return _single(x, _BITS["cutout"], draws, generator)
+
+
+AUGMENT_FNS = {                                  # DiffAugment_tf.py:69-73
+    'color': [rand_brightness, rand_saturation, rand_contrast],
+    'translation': [rand_translation],
+    'cutout': [rand_cutout],
+}

@@ -220,6 +220,9 @@ class BatchLoader:
             raise ValueError("dataset has %d files, fewer than one global batch (%d)" % (len(files), batch_size * world))
         self.files, self.labels = list(files), labels
         self.batch_size, self.image_data, self.device = batch_size, image_data, torch.device(device)
+        self._dev_index = 0
+        if self.device.type == "cuda":
+            self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.rank, self.world = rank, world
         self.rng = np.random.default_rng(seed)          # same seed on every rank: identical permutations
         from concurrent.futures import ThreadPoolExecutor
@@ -231,6 +234,10 @@ class BatchLoader:
 
     def _work(self):
         try:
+            if self.device.type == "cuda":
+                # the current CUDA/HIP device is per THREAD and defaults to 0: without this, ranks 1..N-1 would create
+                # a context (and pinned-allocator state) on GPU 0 from their loader threads
+                torch.cuda.set_device(self._dev_index)
             while not self.stop.is_set():
                 order = self.rng.permutation(len(self.files))
                 per_step = self.batch_size * self.world

@@ -1016,6 +1016,24 @@ class TanhFn(Function):
         return dx
 
 
+class ScaleFn(Function):
+    """a * x with a host scalar a (fp32 tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, a):
+        ctx.a = float(a)
+        y = torch.empty_like(_c(x))
+        check(lib().bg_axpby(f32(_c(x)), ctx.a, f32(y), 0.0, x.numel(), stream()))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(lib().bg_axpby(f32(dy), ctx.a, f32(dx), 0.0, dy.numel(), stream()))
+        return dx, None
+
+
 class AddFn(Function):
     """a + b (residual sums, ops.py:198,266,313)."""
 

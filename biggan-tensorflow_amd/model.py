@@ -766,16 +766,19 @@ class BigGAN(GANBase):
             self._adam(self.g_arena, self.g_learning_rate, with_ema=True, grad_scale=1.0 / vb)
         return self._mean_losses(outs, ("g_adv", "g_reg", "g_loss", "g_cls_loss"))
 
-    def train_step(self, real, labels=None):
+    def train_step(self, real, labels=None, real_g=None):
         """One iteration of BigGAN.py:1061-1084.  ``real`` (and ``labels`` when n_labels > 0) may be lists
-        of --virtual_batches tensors.  After ``capture_graphs()`` the iteration is replayed from HIP graphs."""
+        of --virtual_batches tensors.  ``real_g``: the real batch of the G op - the reference's g_ops pull a FRESH
+        batch from the input iterator (BigGAN.py:1082), which matters for the relativistic losses whose generator
+        loss reads D(real); None re-uses the D op's batch.  After ``capture_graphs()`` the iteration is replayed
+        from HIP graphs."""
         if getattr(self, "_graphs_ready", False):
             if self.acgan and labels is None:
                 labels = self.synthetic_labels(real.shape[0])
-            return self._train_step_graph(real, labels)
-        return self._train_step_eager(real, labels)
+            return self._train_step_graph(real, labels, real_g)
+        return self._train_step_eager(real, labels, real_g)
 
-    def _train_step_eager(self, real, labels=None):
+    def _train_step_eager(self, real, labels=None, real_g=None):
         losses = {}
         first = real[0] if isinstance(real, (list, tuple)) else real
         if self.acgan and labels is None:
@@ -786,8 +789,8 @@ class BigGAN(GANBase):
         if d.get("gp") is not None:
             losses["gp"] = d["gp"]
         if run_g:
-            # (the reference's g_ops pull a fresh real batch from the input iterator; the D step's batch is reused here)
-            g = self.g_step(first.shape[0], after_generator=self._finish_d, real=real if self.relativistic else None)
+            g = self.g_step(first.shape[0], after_generator=self._finish_d,
+                            real=(real_g if real_g is not None else real) if self.relativistic else None)
             losses["g_loss"] = g["g_loss"]
         self._finish_d()
         self.counter += 1
@@ -807,6 +810,7 @@ class BigGAN(GANBase):
         B = B or self.batch_size
         self._g_real = torch.zeros(B, self.img_size, self.img_size, self.c_dim, dtype=torch.float32, device=self.device)
         self._g_labels = (torch.zeros(B, self.n_labels, dtype=torch.float32, device=self.device) if self.acgan else None)
+        self._g_real_g = torch.zeros_like(self._g_real) if self.relativistic else None     # the G op's own real batch
         if getattr(self.d_arena, "lr_dev", None) is None:
             for arena in (self.d_arena, self.g_arena):
                 arena.lr_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -838,7 +842,7 @@ class BigGAN(GANBase):
             self._graph_g = torch.cuda.CUDAGraph()
             self._graph_g.register_generator_state(self.gen)
             with torch.cuda.graph(self._graph_g, pool=self._graph_d.pool()):
-                self._g_out_g = self.g_step(B, real=self._g_real if self.relativistic else None)
+                self._g_out_g = self.g_step(B, real=self._g_real_g if self.relativistic else None)
         finally:
             self._capturing = False
         torch.cuda.synchronize()
@@ -846,8 +850,10 @@ class BigGAN(GANBase):
         self._graphs_ready = True
         return self
 
-    def _train_step_graph(self, real, labels):
+    def _train_step_graph(self, real, labels, real_g=None):
         self._g_real.copy_(real)
+        if self._g_real_g is not None:
+            self._g_real_g.copy_(real_g if real_g is not None else real)
         if self._g_labels is not None:
             self._g_labels.copy_(labels)
         losses = {}
@@ -924,10 +930,14 @@ class BigGAN(GANBase):
                 if iterations is not None and done >= iterations:
                     return
                 batch = data_fn() if data_fn is not None else self.synthetic_batch()
+                real_g = None
+                if self.relativistic and (self.counter - 1) % self.n_critic == 0:  # g_ops take their own batch (BigGAN.py:1082)
+                    nxt = data_fn() if data_fn is not None else self.synthetic_batch()
+                    real_g = nxt[0] if isinstance(nxt, tuple) else nxt
                 if isinstance(batch, tuple):                                       # (images, labels) with --n_labels
-                    losses = self.train_step(batch[0], labels=batch[1])
+                    losses = self.train_step(batch[0], labels=batch[1], real_g=real_g)
                 else:
-                    losses = self.train_step(batch)
+                    losses = self.train_step(batch, real_g=real_g)
                 done += 1
                 vals = {k: float(v.item()) for k, v in losses.items()}
                 print_str = "Step: %5d, time: %4.4f" % (self.counter, time.time() - start_time)   # BigGAN.py:1109-1116
@@ -991,7 +1001,12 @@ class BigGAN(GANBase):
 
     def state_tensors(self):
         """name -> tensor, keyed like a TF checkpoint of the reference graph: variables by their scope
-        names, ``<var>/ExponentialMovingAverage`` shadows, Adam slots ``<var>/Adam`` (m) and ``<var>/Adam_1`` (v)."""
+        names, ``<var>/ExponentialMovingAverage`` shadows, Adam slots ``<var>/Adam`` (m) and ``<var>/Adam_1`` (v).
+
+        Key convention (differs from the reference's swapping_saver, BigGAN.py:1018): here ``<var>`` is the LIVE
+        weight and ``<var>/ExponentialMovingAverage`` its shadow, as in a plain tf.train.Saver.  The reference's
+        swapping saver stores them the other way round (averages under the variable names), so a converter between
+        the two formats must swap the pair for every generator trainable."""
         out = {}
         for k, v in self.store.vars.items():
             out[k] = v.detach()
@@ -1014,7 +1029,24 @@ class BigGAN(GANBase):
         save_file(tensors, os.path.join(d, name + ".safetensors"))
         with open(os.path.join(d, "checkpoint"), "w") as f:
             f.write('model_checkpoint_path: "%s"\n' % name)
+        self._prune_checkpoints(d)
         return os.path.join(d, name + ".safetensors")
+
+    def _prune_checkpoints(self, d):
+        """swapping_saver(max_to_keep=keep_checkpoints) (BigGAN.py:1018): keep the newest N checkpoint files."""
+        keep = int(getattr(self.args, "keep_checkpoints", 0) or 0)
+        if keep <= 0:
+            return
+        pre, suf = self.model_name + ".model-", ".safetensors"
+        found = []
+        for f in os.listdir(d):
+            if f.startswith(pre) and f.endswith(suf):
+                try:
+                    found.append((int(f[len(pre):-len(suf)]), f))
+                except ValueError:
+                    pass
+        for _, f in sorted(found)[:-keep]:
+            os.remove(os.path.join(d, f))
 
     def load_checkpoint(self, checkpoint_path):
         from safetensors.torch import load_file

@@ -496,12 +496,12 @@ def resblock_down_deep(x_init, channels_out, opt, downscale=True, use_bias=True,
     return _add(x, x_skip)
 
 
-def clown_conv(*a, **k):
-    raise NotImplementedError("clown_conv (ops.py:403) is outside the default hot path")
+def clown_conv(x, channels, opt, use_bias=True, scope='clown', z=None):
+    raise NotImplementedError("clown_conv (ops.py:403, --g_mixed_resblocks) is outside the default hot path")
 
 
-def mixed_resblock(*a, **k):
-    raise NotImplementedError("mixed_resblock (ops.py:433) is outside the default hot path")
+def mixed_resblock(x, inner_channels, out_channels, opt, use_bias=False, z=None, scope='res_mixed'):
+    raise NotImplementedError("mixed_resblock (ops.py:433, --g_mixed_resblocks) is outside the default hot path")
 
 
 def self_attention(x, channels, opt, scope='self_attention'):
@@ -585,7 +585,13 @@ def _attention_dual(q, k, v):
 # Sampling
 ##################################################################################
 def global_avg_pooling(x):
-    raise NotImplementedError("global_avg_pooling (ops.py:498) is not used by the default hot path")
+    """ops.py:498-501: tf.reduce_mean(x, axis=[1, 2]) = the sum pool scaled by 1 / (H W)."""
+    if _is_meta(x):
+        return _meta((x.shape[0], x.shape[-1]))
+    inv = 1.0 / float(x.shape[1] * x.shape[2])
+    if _is_dual(x):
+        return Dual(Fn.ScaleFn.apply(Fn.SumPoolFn.apply(x.p), inv), Fn.ScaleFn.apply(Fn.SumPoolFn.apply(x.t), inv))
+    return Fn.ScaleFn.apply(Fn.SumPoolFn.apply(x), inv)
 
 
 def global_sum_pooling(x):

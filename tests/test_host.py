@@ -419,3 +419,35 @@ def test_dataset_loader_shuffles_shards_and_labels(tmp_path):
     files2, labels2 = D.load_data("toy", str(tmp_path / "labels.tsv"), ignore_missing=True, n_labels=2,
                                   root=str(tmp_path / "dataset"))
     assert len(files2) == 13 and labels2[-1] == [0.0, 0.0]
+
+
+def test_keep_checkpoints_prunes_old_files(tmp_path):
+    """--keep_checkpoints N (main.py:18; swapping_saver(max_to_keep=N), BigGAN.py:1018): after N + 2 saves only the N
+    newest checkpoint files remain and the index names the last one."""
+    from biggan_tensorflow_amd import model, scope as S
+    from tests.common import make_args
+    args = make_args(img_size=64, ch=8, batch_size=2, keep_checkpoints=2, checkpoint_dir=str(tmp_path))
+    gan = model.BigGAN(args, device="cpu", store=S.VariableStore("cpu", seed=1)).build_model()
+    for step in (10, 20, 30, 40):
+        gan.save(str(tmp_path), step)
+    d = os.path.join(str(tmp_path), gan.model_dir)
+    files = sorted(f for f in os.listdir(d) if f.endswith(".safetensors"))
+    assert files == ["BigGAN.model-30.safetensors", "BigGAN.model-40.safetensors"]
+    assert 'BigGAN.model-40' in open(os.path.join(d, "checkpoint")).read()
+
+
+def test_reference_names_of_the_boundary_exist_with_reference_signatures():
+    """names a caller of the reference's ops.py / DiffAugment_tf.py may use."""
+    import inspect
+    from biggan_tensorflow_amd import ops, DiffAugment as DA
+    assert list(inspect.signature(ops.clown_conv).parameters) == ["x", "channels", "opt", "use_bias", "scope", "z"]
+    assert list(inspect.signature(ops.mixed_resblock).parameters) == ["x", "inner_channels", "out_channels", "opt",
+                                                                      "use_bias", "z", "scope"]
+    assert list(inspect.signature(ops.global_avg_pooling).parameters) == ["x"]
+    assert set(DA.AUGMENT_FNS) == {"color", "translation", "cutout"}
+    assert [f.__name__ for f in DA.AUGMENT_FNS["color"]] == ["rand_brightness", "rand_saturation", "rand_contrast"]
+    assert inspect.signature(DA.rand_translation).parameters["ratio"].default == 0.125
+    assert inspect.signature(DA.rand_cutout).parameters["ratio"].default == 0.5
+    import torch
+    y = ops.global_avg_pooling(torch.empty(2, 4, 4, 8, device="meta"))
+    assert tuple(y.shape) == (2, 8)
