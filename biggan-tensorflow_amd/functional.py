@@ -100,6 +100,13 @@ class _Mode:
     inputs_only = False
 
 
+class KinkProbe:
+    """Test instrumentation (tests/test_gpu_step.py): when ``sites`` is a list, every activation launch appends what is
+    needed to reconstruct its pre-activation (the tensor itself for a stand-alone PReLU, the batch-norm operands for
+    the fused apply + PReLU kernel), in call order."""
+    sites = None
+
+
 class inputs_only_backward:
     def __enter__(self):
         self.prev, _Mode.inputs_only = _Mode.inputs_only, True
@@ -792,6 +799,9 @@ class BnActFn(Function):
             check(L.bg_bn_apply_act_fwd(f32(x), f32(mean), f32(rstd), f32(gamma_c), f32(beta_c), per_sample,
                                         f32(alpha), f32(y), N, HW, C, stream()))
         ctx.typed = typed
+        if KinkProbe.sites is not None and alpha is not None:
+            KinkProbe.sites.append((getattr(alpha, "bg_name", None), "bn", x.detach().float().clone(), mean.clone(),
+                                    rstd.clone(), gamma_c.detach().clone(), beta_c.detach().clone(), per_sample))
         ctx.x, ctx.mean, ctx.rstd = x, mean, rstd
         ctx.gamma, ctx.beta, ctx.alpha = gamma, beta, alpha
         ctx.gamma_c, ctx.beta_c = gamma_c, beta_c
@@ -865,6 +875,8 @@ class PReluFn(Function):
     def forward(ctx, x, alpha):
         x = _c(x)
         C = x.shape[-1]
+        if KinkProbe.sites is not None:
+            KinkProbe.sites.append((getattr(alpha, "bg_name", None), "act", x.detach().float().clone()))
         y = torch.empty_like(x)
         if x.dtype == torch.float32:
             check(lib().bg_prelu_fwd(f32(x), f32(alpha), f32(y), x.numel() // C, C, stream()))

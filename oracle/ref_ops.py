@@ -279,9 +279,29 @@ def prelu(vs, scope, x):
     return torch.relu(x) + alpha * (x - x.abs()) * 0.5
 
 
+class _Kink:
+    """Test instrumentation for the activations' derivative jump at 0 (PReLU / ReLU / leaky ReLU).  A pre-activation
+    within fp32 rounding of 0 lands on either side of the kink depending on summation order, which changes one
+    element's derivative from 1 to alpha.  ``record`` (a list, when not None) receives (scope, pre-activation) of every
+    activation call in call order; ``flip`` (a dict scope -> list of boolean masks / None, consumed per scope in call
+    order) moves the marked elements to the other side of 0 (x -> -x there: a value change of ~1e-7; the derivative
+    side the product took)."""
+    record = None
+    flip = None
+
+
+KINK = _Kink()
+
+
 def activation(vs, scope, x, opt):
     """opt['act'] (BigGAN.py:71-83): 'prelu' (ops.py:532, variable <scope>/alpha), 'relu' (529) or
     'lrelu' = tf.nn.leaky_relu(x, 0.2) (525, BigGAN.py:79)."""
+    if KINK.flip is not None and KINK.flip.get(scope):
+        m = KINK.flip[scope].pop(0)
+        if m is not None:
+            x = x + (-2.0) * x.detach() * m.to(x.dtype)
+    if KINK.record is not None:
+        KINK.record.append((scope, x.detach().clone()))
     kind = opt.get("act", "prelu")
     if kind == "prelu":
         return prelu(vs, scope, x)

@@ -130,3 +130,91 @@ def test_full_size_iteration_is_reproducible_and_sane():
     assert not torch.equal(gan.store.vars["generator/first/dense2/u"], u0)
     assert not torch.equal(gan.g_arena.params, w0) and not torch.equal(gan.g_arena.ema, gan.g_arena.params)
     assert torch.isfinite(gan.g_arena.grads).all() and torch.isfinite(gan.g_arena.params).all()
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE configs 3, 4, 5 at their real sizes, bf16-resident precision (the oracle is far too slow here: properties)
+# ------------------------------------------------------------------------------------------
+# (kind, N, H, Cin, Cout, k, s): layer shapes of G-128 / D-128 at ch = 96, per-GPU batch 32 (D sees 2B = 64)
+C3_LAYERS = [
+    ("deconv", 32, 4, 1536, 1536, 4, 2), ("deconv", 32, 16, 768, 384, 4, 2), ("deconv", 32, 64, 192, 96, 4, 2),
+    ("deconv", 32, 128, 96, 96, 3, 1), ("deconv", 32, 32, 384, 384, 3, 1),
+    ("conv", 64, 64, 96, 96, 3, 1), ("conv", 64, 64, 96, 192, 3, 2), ("conv", 64, 8, 768, 1536, 3, 2),
+    ("conv", 64, 4, 1536, 1536, 3, 1), ("conv", 32, 64, 192, 144, 1, 1),
+]
+
+
+@pytest.mark.parametrize("kind,N,H,Cin,Cout,k,s", C3_LAYERS)
+def test_adjoint_identities_config3_bf16_resident(kind, N, H, Cin, Cout, k, s):
+    """<y, g> = <x, dgrad(g)> = <w, wgrad(x, g)> on the bf16-resident kernels at BASELINE config 3's layer shapes
+    (ch = 96: 96 ... 1536 channels, batch 32 / 64).  Each product is rounded to bf16 once more than the other side of
+    its identity, so the tolerance is 2e-2 of |y||g| (as for the staged mode)."""
+    Fn, hip = _mods()
+    Fn.set_precision("bf16")
+    try:
+        x = _rnd((N, H, H, Cin), 1).bfloat16().requires_grad_(True)
+        if kind == "conv":
+            w = _rnd((k, k, Cin, Cout), 2, 0.05).requires_grad_(True)
+            Ho = H // s
+            pad = 1 if k == 3 else 0
+            y = Fn.Conv2dFn.apply(x, w, None, s, pad, Ho, Ho, hip.PAD_REFLECT)
+        else:
+            w = _rnd((k, k, Cout, Cin), 2, 0.05).requires_grad_(True)
+            y = Fn.Deconv2dFn.apply(x, w, None, s, 1, None)
+        assert y.dtype == torch.bfloat16
+        g = _rnd(tuple(y.shape), 3).bfloat16()
+        y.backward(g)
+        lhs = _dot(y.detach().float(), g.float())
+        scale = float(y.detach().double().norm() * g.double().norm())
+        tol = 2e-2 * scale
+        wb = w.detach().bfloat16().float()          # the kernels see the packed bf16 copy of w
+        assert abs(lhs - _dot(x.detach().float(), x.grad.float())) <= tol
+        assert abs(lhs - _dot(wb, w.grad)) <= tol
+        assert torch.isfinite(y.float()).all()
+    finally:
+        Fn.set_precision("fp32")
+
+
+@pytest.mark.parametrize("img,ch,B", [(128, 96, 32), (256, 96, 32), (512, 128, 64)])
+def test_full_size_bf16_iteration_configs_3_4_5(img, ch, B):
+    """One D + G iteration of BASELINE configs 3, 4 and 5 at the per-GPU batch BASELINE.json states (32 / 32 / 64),
+    --precision bf16: finite losses in the range of a random-init hinge GAN, the D op's forward bit-reproducible from
+    identical state and inputs, gradients reproducible (no atomics in any GEMM), every gradient and parameter finite,
+    u / Adam / EMA state advancing.  (Config 5 needs ~150 GB of HBM for its activations at batch 64.)"""
+    from tests.common import make_args
+    import biggan_tensorflow_amd  # noqa: F401
+    from biggan_tensorflow_amd import model, scope as S, functional as Fn
+    from biggan_tensorflow_amd.DiffAugment import draw
+    args = make_args(img_size=img, ch=ch, batch_size=B, precision="bf16")
+    try:
+        gan = model.BigGAN(args, store=S.VariableStore("cuda", seed=42)).build_model()
+        real = gan.synthetic_batch(B)
+        z = gan.sample_z(B)
+        dr, df = draw(B, img, generator=gan.gen, device="cuda"), draw(B, img, generator=gan.gen, device="cuda")
+        state = gan.store.export_arrays()
+        a = gan.d_step(real, z, dr, df, apply=False)
+        la, fa = a["d_loss"].item(), a["fake"].clone()
+        ga = gan.d_arena.grads.clone()
+        del a
+        gan.store.load_arrays(state, reset_ema=False)
+        b = gan.d_step(real, z, dr, df, apply=False)
+        assert b["d_loss"].item() == la and torch.equal(b["fake"], fa)          # forward: bit-identical
+        del b
+        assert torch.isfinite(ga).all() and float(ga.abs().max()) > 0
+        rel = float((gan.d_arena.grads - ga).double().norm() / ga.double().norm())
+        assert rel < 1e-4, rel
+        assert 0.2 < la < 20.0, la
+        del ga, fa
+        gan.store.load_arrays(state, reset_ema=False)
+        u0 = gan.store.vars["generator/first/dense2/u"].clone()
+        w0 = gan.g_arena.params[:4096].clone()
+        losses = gan.train_step(real)
+        assert all(np.isfinite(v.item()) for v in losses.values())
+        assert not torch.equal(gan.store.vars["generator/first/dense2/u"], u0)
+        assert not torch.equal(gan.g_arena.params[:4096], w0)
+        assert torch.isfinite(gan.g_arena.grads).all() and torch.isfinite(gan.g_arena.params).all()
+        assert torch.isfinite(gan.d_arena.grads).all() and torch.isfinite(gan.d_arena.params).all()
+    finally:
+        Fn.set_precision("fp32")
+        gan = None
+        torch.cuda.empty_cache()

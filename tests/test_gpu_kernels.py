@@ -713,7 +713,7 @@ def test_pooling_tanh_scaleadd():
 # ------------------------------------------------------------------------------------------
 # DiffAugment (DiffAugment_tf.py)
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("S", [8, 32, 64, 128])
+@pytest.mark.parametrize("S", [8, 32, 64, 128, 256, 512])      # 256 / 512: BASELINE configs 4 and 5
 def test_diffaugment_translation_cutout_bit_exact(S):
     from biggan_tensorflow_amd.DiffAugment import DiffAugment, draws_to_device
     rng = np.random.default_rng(S)

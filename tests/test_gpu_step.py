@@ -49,9 +49,10 @@ def _scale_ref(name, grads):
 def _noise_driven(name, grads=None):
     """Adam with beta1 = 0 turns ANY non-zero gradient into a +-lr-sized update, so the post-step value
     of a parameter whose exact gradient is zero is rounding noise on every platform (TensorFlow too)."""
-    if name.endswith("self_attention/f_conv/bias"):
-        return True
-    return grads is not None and name in grads and _vanishing(name, grads)
+    nd = name.endswith("self_attention/f_conv/bias") or (grads is not None and name in grads and _vanishing(name, grads))
+    if nd:
+        EXEMPT["noise_driven_tensors"] += 1       # (an upper bound: the same tensor is asked about several times)
+    return nd
 
 
 def _state_err(hip_v, ref_v, g_ref=None):
@@ -61,10 +62,12 @@ def _state_err(hip_v, ref_v, g_ref=None):
     left out of the comparison (they are compared as gradients, by norm, in _check_grads)."""
     a = np.asarray(hip_v, np.float64).ravel()
     b = np.asarray(ref_v, np.float64).ravel()
+    EXEMPT["state_elements"] += a.size
     if g_ref is not None:
         g = np.abs(np.asarray(g_ref, np.float64).ravel())
         keep = g > 1e-3 * max(g.max(), 1e-300)
         if keep.any():
+            EXEMPT["masked_state_elements"] += int(a.size - keep.sum())
             a, b = a[keep], b[keep]
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
@@ -86,55 +89,118 @@ def _tol(name):
     return 5e-2 if name.endswith("self_attention/gamma") else GRAD_TOL
 
 
-def _grads_ok(gan, ref_grads):
-    for k, g in ref_grads.items():
-        e = _grad_err(t2n(gan.store.vars[k].bg_grad), g.numpy(), _scale_ref(k, ref_grads))
-        if not e < _tol(k):
-            return (k, e)
-    return None
+# ------------------------------------------------------------------------------------------
+# Exemption accounting: everything the comparison leaves out is counted, printed (pytest -rA / -s) and bounded.
+# ------------------------------------------------------------------------------------------
+EXEMPT = {"kink_elements": 0, "kink_unsynced_ops": 0, "vanishing_tensors": 0, "noise_driven_tensors": 0,
+          "masked_state_elements": 0, "state_elements": 0, "grad_tensors": 0}
+MAX_KINK_ELEMENTS = 32           # per test: pre-activations within fp32 rounding of 0 whose side differs
+MAX_VANISHING = 12               # per test: bias tensors whose exact gradient is zero
+MAX_MASKED_FRACTION = 0.10       # post-step elements left out because only the SIGN of a ~0 gradient moved them
 
 
-def _check_grads(tag, gan, ref_grads, rerun=None):
-    """PReLU's gradient is discontinuous at 0.  An activation within fp32 rounding (~1e-7) of the kink
-    can land on either side of it, in which case one element of dx changes by (1 - alpha) * dy and, if
-    dy is an outlier there, a whole tensor moves by ~1e-3 (measured: exactly ONE element differs between
-    two HIP runs of the same step whose float-atomic reductions summed in a different order; all other
-    elements agree to 1e-6).  The float64 oracle has no such noise, so a failing comparison is re-run
-    (up to 3 attempts in total) before it counts."""
-    bad = _grads_ok(gan, ref_grads)
-    for _ in range(2):
-        if bad is None or rerun is None:
+@pytest.fixture(autouse=True)
+def _exemption_report(request):
+    for k in EXEMPT:
+        EXEMPT[k] = 0
+    yield
+    if EXEMPT["grad_tensors"]:
+        frac = EXEMPT["masked_state_elements"] / max(EXEMPT["state_elements"], 1)
+        print("\n[parity exemptions] %s: kink elements flipped in the oracle %d (unsynced ops %d), vanishing-gradient "
+              "bias tensors %d of %d gradient tensors, noise-driven state tensors %d, masked state elements %.3f %%"
+              % (request.node.name, EXEMPT["kink_elements"], EXEMPT["kink_unsynced_ops"], EXEMPT["vanishing_tensors"],
+                 EXEMPT["grad_tensors"], EXEMPT["noise_driven_tensors"], 100.0 * frac))
+        assert EXEMPT["kink_elements"] <= MAX_KINK_ELEMENTS
+        assert EXEMPT["vanishing_tensors"] <= MAX_VANISHING
+        assert frac <= MAX_MASKED_FRACTION
+
+
+def _hip_pre(site):
+    """Pre-activation of one recorded product-side activation launch, float64 numpy."""
+    if site[1] == "act":
+        return site[2].double().cpu().numpy()
+    _, _, x, mean, rstd, gamma, beta, per_sample = site
+    x, mean, rstd = x.double(), mean.double(), rstd.double()
+    gamma, beta = gamma.double(), beta.double()
+    if per_sample:
+        gamma, beta = gamma[:, None, None, :], beta[:, None, None, :]
+    return (((x - mean) * rstd) * gamma + beta).cpu().numpy()
+
+
+def _kink_synced(tr, run_oracle, run_hip):
+    """Run one op on both sides with the activation probes on, find the pre-activations whose side of 0 differs
+    (they must lie within 1e-5 of the tensor's rms of 0 in the float64 oracle - anything else is a real forward
+    mismatch and fails), and re-run the ORACLE with exactly those elements moved to the product's side of the kink.
+    The product runs once; nothing is retried and no batch is swapped.  Returns (oracle result, product result)."""
+    from oracle import ref_ops as R
+    from biggan_tensorflow_amd import functional as Fn
+    R.KINK.record, R.KINK.flip = [], None
+    Fn.KinkProbe.sites = []
+    try:
+        ro = run_oracle()
+        ho = run_hip()
+    finally:
+        rec, R.KINK.record = R.KINK.record, None
+        sites, Fn.KinkProbe.sites = Fn.KinkProbe.sites, None
+    o_by, h_by = {}, {}
+    for scope, x in rec:
+        o_by.setdefault(scope, []).append(x)
+    for st in sites:
+        name = st[0]
+        if name is None or not name.endswith("/alpha"):
+            h_by = None
             break
-        rerun()
-        bad = _grads_ok(gan, ref_grads)
-    if bad is not None:
-        raise _KinkFlip(repr((tag,) + bad))
+        h_by.setdefault(name[:-len("/alpha")], []).append(_hip_pre(st))
+    flips, total = {}, 0
+    ok = h_by is not None and set(h_by) == set(o_by)
+    if ok:
+        for scope, calls in o_by.items():
+            po = np.concatenate([c.double().numpy() for c in calls], axis=0)
+            ph = np.concatenate(h_by[scope], axis=0)
+            if po.shape != ph.shape:
+                ok = False
+                break
+            m = (ph > 0) != (po > 0)
+            n = int(m.sum())
+            if n:
+                rms = float(np.sqrt(np.mean(po * po))) + 1e-30
+                worst = float(np.abs(po[m]).max())
+                assert worst <= 1e-5 * rms, ("activation sign differs away from the kink", scope, n, worst, rms)
+                total += n
+                off, per_call = 0, []
+                for c in calls:
+                    per_call.append(torch.tensor(m[off:off + c.shape[0]]))
+                    off += c.shape[0]
+                flips[scope] = per_call
+    if not ok:
+        EXEMPT["kink_unsynced_ops"] += 1          # (relu / lrelu activations, gradient-penalty passes: no site names)
+        return ro, ho
+    if total:
+        EXEMPT["kink_elements"] += total
+        tr.vs.state_updates.clear()
+        R.KINK.flip = flips
+        try:
+            ro = run_oracle()
+        finally:
+            R.KINK.flip = None
+    return ro, ho
 
 
-class _KinkFlip(AssertionError):
-    pass
+def _check_grads(tag, gan, ref_grads):
+    """Every gradient tensor within its tolerance, once (the product's forward pass is bit-reproducible: fp64
+    accumulators in every forward reduction, so a re-run could not change the outcome)."""
+    for k, g in ref_grads.items():
+        EXEMPT["grad_tensors"] += 1
+        if _vanishing(k, ref_grads):
+            EXEMPT["vanishing_tensors"] += 1
+        e = _grad_err(t2n(gan.store.vars[k].bg_grad), g.numpy(), _scale_ref(k, ref_grads))
+        assert e < _tol(k), (tag, k, e)
 
 
 def _run_parity(tr, gan, batch, check_state=True):
     """(1) first-step gradients of both train ops from IDENTICAL state (no update applied);
-    (2) one full iteration (D update, then G update) and the state it leaves behind.
-
-    A PReLU-kink flip (see _check_grads) is a property of (inputs, build): it is deterministic for a given batch,
-    and a change of GEMM tiling moves it to other batches.  A gradient comparison that still fails after its
-    re-runs is therefore repeated ONCE on a second synthetic batch (fresh oracle and model state): a real defect
-    fails on both, a kink flip (one activation within 1e-7 of zero) practically never does."""
-    start_o, start_h = tr.vs.export(), gan.store.export_arrays()
-    try:
-        return _run_parity_once(tr, gan, batch, check_state)
-    except _KinkFlip as first:
-        tr.vs.state_updates.clear()
-        tr.vs.load(start_o)
-        gan.store.load_arrays(start_h, reset_ema=True)
-        alt = RM.synthetic_batch(tr.cfg, 7919 + int(batch["real"].shape[0]), batch["real"].shape[0])
-        try:
-            return _run_parity_once(tr, gan, alt, check_state)
-        except AssertionError as second:
-            raise AssertionError("parity failed on two independent batches: %s ; %s" % (first, second))
+    (2) one full iteration (D update, then G update) and the state it leaves behind."""
+    return _run_parity_once(tr, gan, batch, check_state)
 
 
 def _run_parity_once(tr, gan, batch, check_state=True):
@@ -161,8 +227,9 @@ def _run_parity_once(tr, gan, batch, check_state=True):
         hkw_g = dict(hkw_g, cls_z=cu(batch["cls_z_g"]))
 
     # ---------------- gradient parity, D op ----------------
-    ro = tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], apply=False, **okw_d)
-    ho = gan.d_step(real, z_d, a_r, a_fd, apply=False, **hkw_d)
+    ro, ho = _kink_synced(
+        tr, lambda: tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], apply=False, **okw_d),
+        lambda: gan.d_step(real, z_d, a_r, a_fd, apply=False, **hkw_d))
     assert _loss_close(ho["d_loss"].item(), ro["d_loss"].item()), (ho["d_loss"].item(), ro["d_loss"].item())
     if "gp" in batch:
         assert _loss_close(ho["gp"].item(), ro["gp"].item()), (ho["gp"].item(), ro["gp"].item())
@@ -171,16 +238,13 @@ def _run_parity_once(tr, gan, batch, check_state=True):
     assert rel_err(t2n(ho["real_logits"]), ro["real_logits"].detach().numpy()) < GRAD_TOL
     assert rel_err(t2n(ho["fake_logits"]), ro["fake_logits"].detach().numpy()) < GRAD_TOL
     assert rel_err(t2n(ho["fake"]), ro["fake"].detach().numpy()) < GRAD_TOL
-    def rerun_d():
-        gan.store.load_arrays(hip0, reset_ema=False)
-        gan.d_step(real, z_d, a_r, a_fd, apply=False, **hkw_d)
-    _check_grads("d grad", gan, ro["grads"], rerun_d)
+    _check_grads("d grad", gan, ro["grads"])
     tr.vs.state_updates.clear()
     gan.store.load_arrays(hip0, reset_ema=False)                  # undo the in-place u / BN-stat updates
 
     # ---------------- gradient parity, G op ----------------
-    ro = tr.g_step(batch["z_g"], batch["aug_fake_g"], apply=False, **okw_g)
-    ho = gan.g_step(B, z_g, a_fg, apply=False, **hkw_g)
+    ro, ho = _kink_synced(tr, lambda: tr.g_step(batch["z_g"], batch["aug_fake_g"], apply=False, **okw_g),
+                          lambda: gan.g_step(B, z_g, a_fg, apply=False, **hkw_g))
     if cfg.n_labels:
         assert _loss_close(ho["g_cls_loss"].item(), ro["g_cls_loss"].item())
     ro_adv = ro["g_adv"].item() + (ro["g_cls_loss"].item() if cfg.n_labels else 0.0)   # product folds the label loss in
@@ -189,10 +253,7 @@ def _run_parity_once(tr, gan, batch, check_state=True):
     if cfg.g_regularization != "none":
         assert _loss_close(ho["g_reg"].item(), ro["g_reg"].item())
     assert rel_err(t2n(ho["fake_logits"]), ro["fake_logits"].detach().numpy()) < GRAD_TOL
-    def rerun_g():
-        gan.store.load_arrays(hip0, reset_ema=False)
-        gan.g_step(B, z_g, a_fg, apply=False, **hkw_g)
-    _check_grads("g grad", gan, ro["grads"], rerun_g)
+    _check_grads("g grad", gan, ro["grads"])
     tr.vs.state_updates.clear()
     gan.store.load_arrays(hip0, reset_ema=False)
     if not check_state:
@@ -249,6 +310,27 @@ def test_step_parity_small(img, ch, zd, B):
     _run_parity(tr, gan, batch)
 
 
+@pytest.mark.parametrize("img,ch", [(256, 8), (512, 8), (256, 16)])
+def test_step_parity_256_and_512_topologies(img, ch):
+    """BASELINE configs 4 and 5 topologies (BigGAN.py:292-293, 609-610) at small width: two-block stages with the
+    cumulative scope names (resblock_up_8_0, resblock_up_8_0_1; BigGAN.py:455, 627), 6 / 7 z chunks, self-attention
+    still on the 64 x 64 map at C = 4c (generator) and 2c (discriminator; at ch = 8 its d = 2 takes the materialised
+    softmax path), DiffAugment at S = 256 / 512.  Same gates as every other step-parity test, B = 2."""
+    tr = oracle_trainer(img, ch, 256, 2)
+    gan = hip_model_like(tr)
+    names = set(gan.store.vars)
+    assert "generator/resblock_up_8_0/res1/deconv_0/kernel" in names
+    assert "generator/resblock_up_8_0_1/res1/deconv_0/kernel" in names          # the cumulative-suffix quirk
+    if img == 512:
+        assert "generator/resblock_up_1_0_1/res2/deconv_0/kernel" in names
+        assert "discriminator/resblock_down_2_0_1/res1/conv_0/kernel" in names
+    else:
+        assert "discriminator/resblock_down_8_0_1/res1/conv_0/kernel" in names
+    assert set(tr.vs.vars) == names
+    batch = RM.synthetic_batch(tr.cfg, 23, 2)
+    _run_parity(tr, gan, batch, check_state=False)
+
+
 def test_step_parity_no_regulariser_no_augment():
     tr = oracle_trainer(64, 8, 64, 4, g_regularization="none", da_policy="")
     gan = hip_model_like(tr)
@@ -278,12 +360,10 @@ def test_plumbing_config_img64_ch32_batch16():
     """BASELINE config 1 (plumbing): smallest reference-supported size, ch=32, batch=16, fp32."""
     tr = oracle_trainer(64, 32, 256, 16)
     gan = hip_model_like(tr)
-    # Seed scan at this size (scratch run, round 1): batch seeds 19 and 29 give every gradient tensor to
-    # <= 3e-6 relative L2; seeds 9 and 39 each put one activation within fp32 rounding of the PReLU kink
-    # (see _check_grads), which moves single tensors by 2e-3 / 8e-4.  The forward pass is reproducible
-    # run to run (fp64 accumulators in every forward reduction), so the choice of seed is stable.
-    batch = RM.synthetic_batch(tr.cfg, 29, 16)
-    _run_parity(tr, gan, batch, check_state=False)
+    # Batch seed 9 is one of the two seeds (9, 39) that round 1 avoided because ONE activation lies within fp32
+    # rounding of the PReLU kink: the kink synchronisation of _kink_synced handles it (reported as an exemption).
+    batch = RM.synthetic_batch(tr.cfg, 9, 16)
+    _run_parity(tr, gan, batch, check_state=True)
 
 
 def test_step_parity_class_conditional():
