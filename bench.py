@@ -5,19 +5,28 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one D update + one G update (BigGAN.py:1061-1084, n_critic = 1) on a synthetic
-class-free batch already resident in HBM.  The default workload is BASELINE config 2
-(BigGAN-128, ch=64, batch 64 per GPU, fp32); per-GPU work is fixed as N grows (weak scaling).
+One "step" = one D update + one G update (BigGAN.py:1061-1084, n_critic = 1) on a synthetic batch already resident
+in HBM.
 
-Prints ONE JSON line on rank 0 with the throughput, the MFMA roofline of the dominant kernel
-family (conv / transposed conv / matmul implicit-GEMM launches, timed with HIP events on their
-stream in a second pass over the same steps) and a CPU baseline: the oracle (a torch-CPU
-restatement, "port" - TensorFlow is not available) timed on this host's cores on a bounded sample.
+  N = 1 (default)  headline = BASELINE config 2 (BigGAN-128, ch 64, batch 64, fp32: the reference's precision), plus a
+                   "target" object: BASELINE config 3 (BigGAN-128, ch 96, bf16) at its GLOBAL batch 256 on this one GPU -
+                   the 1-GPU point of the strong-scaling curve - with its --g_regularization none and --da_policy ""
+                   companions.
+  N > 1            config 3 at FIXED global batch 256 (256 / N images per rank), "scaling": "strong"
+                   (--scaling weak keeps 32 images per rank instead).
+
+Prints ONE JSON line on rank 0 with the throughput, the MFMA roofline of the convolution / attention GEMM launches
+(timed with HIP events on their stream in a second pass over the same steps; algorithmic FLOPs only - the
+regulariser's Gram matrices and dense layers are excluded) and a CPU baseline: the oracle (a torch-CPU restatement,
+"port" - TensorFlow is not available) timed on this host's cores on a bounded sample.
 """
 import argparse
+import collections
+import ctypes
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,17 +39,18 @@ WORKLOADS = {
     "c1": (64, 32, 16, "plumbing: BigGAN-64 ch=32 batch=16 fp32 (BASELINE config 1)"),
     "c3fp32": (128, 96, 32, "BigGAN-128 ch=96 batch=32/GPU fp32 (config 3 shape, fp32 kernels)"),
     # bf16: bf16-resident activations + packed bf16 weights, fp32 accumulate / master weights / optimiser (--precision bf16)
-    "c3": (128, 96, 32, "BigGAN-128 ch=96 batch=32/GPU (256 over 8 GPUs) bf16 (BASELINE config 3)"),
+    "c3": (128, 96, 32, "BigGAN-128 ch=96 bf16 (BASELINE config 3: global batch 256, 32/GPU over 8 GPUs)"),
     "c2bf16": (128, 64, 64, "BigGAN-128 ch=64 batch=64/GPU bf16 (config 2 shape)"),
-    "c4": (256, 96, 32, "BigGAN-256 ch=96 batch=32/GPU (256 over 8 GPUs) bf16 + DiffAugment (BASELINE config 4)"),
-    "c5": (512, 128, 64, "BigGAN-512 ch=128 batch=64/GPU (512 over 8 GPUs) bf16 (BASELINE config 5)"),
+    "c4": (256, 96, 32, "BigGAN-256 ch=96 bf16 + DiffAugment (BASELINE config 4: global batch 256, 32/GPU over 8 GPUs)"),
+    "c5": (512, 128, 64, "BigGAN-512 ch=128 bf16 (BASELINE config 5: global batch 512, 64/GPU over 8 GPUs)"),
     # round-1 arithmetic for comparison: fp32 tensors, operands rounded to bf16 while staged (--precision bf16-staged)
     "c3staged": (128, 96, 32, "BigGAN-128 ch=96 batch=32/GPU, fp32 tensors with bf16-staged conv operands"),
 }
 BF16_WORKLOADS = ("c3", "c2bf16", "c4", "c5", "c3staged")
+GLOBAL_BATCH = {"c3": 256, "c4": 256, "c5": 512}      # BASELINE.json: fixed global batch of the 8-GPU configs
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-BF16_MFMA_PEAK_TFLOPS = 2516.6     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
+BF16_MFMA_PEAK_TFLOPS = 2516.6     # MI355X_MICROARCH.md: bf16 MFMA, dense (no sparsity)
 
 
 def step_flops_per_image(img, ch):
@@ -133,24 +143,153 @@ def cpu_baseline(img, ch, sample_batch, steps, note=lambda m: None):
                       "TensorFlow, the reference's substrate, is not installed)" % (steps, sample_batch, dt)}
 
 
+def resolve_workload(workload, world, scaling="", batch=0):
+    """(workload name, per-GPU batch, "strong" | "weak") of a run.  One GPU: config 2 unless told otherwise.  N > 1:
+    BASELINE config 3 with its FIXED global batch 256 split into equal shards (strong scaling); --scaling
+    weak keeps the per-GPU batch of the workload table; --batch overrides the per-GPU batch."""
+    name = workload or ("c2" if world == 1 else "c3")
+    B = WORKLOADS[name][2]
+    mode = "weak"
+    if world > 1:
+        mode = scaling or ("strong" if name in GLOBAL_BATCH else "weak")
+        if mode == "strong":
+            gb = GLOBAL_BATCH.get(name, B * 8)
+            if gb % world:
+                raise SystemExit("global batch %d is not divisible by %d ranks" % (gb, world))
+            B = gb // world
+    if batch:
+        B = batch
+    return name, B, mode
+
+
 def pmc_traffic(workload):
     """HBM bytes per implicit-GEMM launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     over this same command (profiles/README.md; counters cannot be read from inside the process)."""
     import glob
     import re
-    base = {"c2bf16": "c2", "c3fp32": "c3"}.get(workload, workload)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % workload)) or
-                   glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % base)))
-    if not files or not files[-1].endswith("_pmc_%s.json" % workload):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % workload)))
+    if not files:
         return None, None
     with open(files[-1]) as fh:
         d = json.load(fh)
     n = b = 0.0
     for k, e in d.items():
-        if re.search(r"\b((nn|tn)_kernel|attn_(fwd|bwd))", k) and "hbm_read_bytes_per_launch" in e:
+        if re.search(r"\b((nn|tn)(16)?_kernel|attn(16)?_(fwd|bwd))", k) and "hbm_read_bytes_per_launch" in e:
             n += e["launches"]
             b += e["launches"] * (e["hbm_read_bytes_per_launch"] + e.get("hbm_write_bytes_per_launch", 0.0))
     return (b / n if n else None), os.path.relpath(files[-1], ROOT)
+
+
+ALGORITHMIC_TAGS = ("conv2d_", "deconv2d_", "attention")     # launches whose FLOPs SURVEY 8(d) counts
+
+
+def roofline_pass(gan, real, nsteps, peak, fpi, B, ms_per_step, workload):
+    """Second pass over the same steps with every GEMM-family launch bracketed by HIP events on its stream."""
+    import torch
+    from biggan_tensorflow_amd import hip
+    L = hip.lib()
+    L.bg_prof_reset()
+    L.bg_prof_enable(1)
+    for _ in range(nsteps):
+        gan.train_step(real)
+    torch.cuda.synchronize()
+    fd, path = tempfile.mkstemp(suffix=".csv")
+    os.close(fd)
+    L.bg_prof_dump(path.encode())
+    ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    L.bg_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+    L.bg_prof_enable(0)
+    by_tag = collections.OrderedDict()
+    alg_ms = alg_fl = all_ms = 0.0
+    with open(path) as fh:
+        next(fh)
+        for line in fh:
+            tag, f, t = line.rsplit(",", 2)
+            f, t = float(f), float(t)
+            all_ms += t
+            if tag.startswith(ALGORITHMIC_TAGS):
+                alg_ms += t
+                alg_fl += f
+                e = by_tag.setdefault(tag, [0.0, 0.0, 0])
+                e[0] += t
+                e[1] += f
+                e[2] += 1
+    os.unlink(path)
+    achieved = alg_fl / (alg_ms * 1e-3) / 1e12 if alg_ms > 0 else 0.0
+    dom_tag, dom = max(by_tag.items(), key=lambda kv: kv[1][0]) if by_tag else ("", [0.0, 0.0, 0])
+    dom_tf = dom[1] / (dom[0] * 1e-3) / 1e12 if dom[0] > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(workload)
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+            "traffic_source": traffic_src,
+            "kernel": "conv / transposed-conv implicit-GEMM launches (forward, input gradient, weight gradient) and the "
+                      "fused attention: the launches whose FLOPs SURVEY 8(d) counts",
+            "launches_per_step": int(sum(e[2] for e in by_tag.values()) // nsteps),
+            "gemm_ms_per_step": round(alg_ms / nsteps, 3), "gemm_flops_per_step": alg_fl / nsteps,
+            "all_gemm_family_ms_per_step": round(all_ms / nsteps, 3),
+            "dominant": {"launch": dom_tag, "launches_per_step": dom[2] // nsteps, "ms_per_step": round(dom[0] / nsteps, 3),
+                         "achieved": round(dom_tf, 2), "frac": round(dom_tf / peak, 4)},
+            "step_algorithmic_flops": fpi * B,
+            "step_frac_of_peak": round(fpi * B / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
+
+
+def run_workload(name, B, a, world, rank, note, extra=(), steps=None, warmup=None, roofline=True, graph=False):
+    """Build the model for one workload, time `steps` iterations, optionally the roofline pass.  Returns a dict."""
+    import torch
+    from biggan_tensorflow_amd import main as M, model, scope as S
+    img, ch, _, desc = WORKLOADS[name]
+    bf16 = name in BF16_WORKLOADS
+    precision = a.precision or ("bf16-staged" if name == "c3staged" else "bf16" if bf16 else "fp32")
+    kw = dict(da_policy=a.da_policy, g_regularization=a.g_regularization)
+    kw.update(dict(extra))
+    argv = ["--gan_type", a.gan_type, "--img_size", str(img), "--ch", str(ch), "--batch_size", str(B),
+            "--da_policy", kw["da_policy"], "--g_regularization", kw["g_regularization"], "--n_labels", str(a.n_labels),
+            "--precision", precision]
+    args = M.parse_args(argv, make_dirs=False)
+    peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+    gan = model.BigGAN(args, device="cuda", store=S.VariableStore("cuda", seed=42)).build_model()
+    real = gan.synthetic_batch(B)
+    steps = steps or a.steps
+    warmup = a.warmup if warmup is None else warmup
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    if graph:
+        gan.capture_graphs(B)
+    note("model built: %s, batch %d/GPU%s" % (desc, B, " (HIP-graph replay)" if graph else ""))
+    for i in range(warmup):
+        gan.train_step(real)
+        torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = gan.train_step(real)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / steps * 1e3
+    value = B * world * steps / dt
+    note("%s: timed %d steps: %.1f ms/step, %.1f images/sec" % (name, steps, ms_per_step, value))
+    fpi, _, _ = step_flops_per_image(img, ch)
+    out = {"workload": desc, "img_size": img, "ch": ch, "per_gpu_batch": B, "global_batch": B * world,
+           "precision": precision,
+           "storage_dtype": ("bf16 activations + packed bf16 conv weights; fp32 master weights, optimiser, statistics"
+                             if precision == "bf16" else "fp32"),
+           "da_policy": kw["da_policy"], "g_regularization": kw["g_regularization"],
+           "value": round(value, 2), "ms_per_step": round(ms_per_step, 3), "steps": steps,
+           "step_frac_of_peak": round(fpi * B / (ms_per_step * 1e-3) / 1e12 / peak, 4),
+           "losses": {k: round(float(v.item()), 5) for k, v in losses.items()}}
+    if roofline and not graph:
+        out["roofline"] = roofline_pass(gan, real, min(steps, 3), peak, fpi, B, ms_per_step, name)
+        note("%s: roofline pass done" % name)
+    del gan, real
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -158,8 +297,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", type=str, default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", type=str, default="", choices=[""] + sorted(WORKLOADS),
+                    help="default: c2 on one GPU (+ the config-3 target object), c3 at fixed global batch 256 on N > 1")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--scaling", type=str, default="", choices=["", "strong", "weak"],
+                    help="N > 1: strong (default) = BASELINE's fixed global batch split over the ranks; weak = per-GPU batch fixed")
     ap.add_argument("--da_policy", type=str, default="full")
     ap.add_argument("--g_regularization", type=str, default="ortho_cosine")
     ap.add_argument("--n_labels", type=int, default=0, help="class-conditional variant: synthetic one-hot labels")
@@ -169,13 +311,13 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the iteration from captured HIP graphs (N=1 only)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--no_target", action="store_true", help="N = 1 default run: skip the config-3 target object")
     a = ap.parse_args()
 
     t_start = time.perf_counter()
     import torch
     import biggan_tensorflow_amd  # noqa: F401
-    from biggan_tensorflow_amd import hip, main as M, model, parallel, scope as S
-    import ctypes
+    from biggan_tensorflow_amd import parallel
 
     rank, world, local = parallel.init_from_env()
     if world != a.gpus and world > 1:
@@ -184,78 +326,36 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     torch.cuda.set_device(local % torch.cuda.device_count())   # (ranks share a card only in gloo rehearsals)
 
-    img, ch, B, desc = WORKLOADS[a.workload]
-    if a.batch:
-        B = a.batch
-    argv = ["--gan_type", a.gan_type, "--img_size", str(img), "--ch", str(ch), "--batch_size", str(B),
-            "--da_policy", a.da_policy, "--g_regularization", a.g_regularization, "--n_labels", str(a.n_labels)]
-    bf16 = a.workload in BF16_WORKLOADS
-    precision = a.precision or ("bf16-staged" if a.workload == "c3staged" else "bf16" if bf16 else "fp32")
-    argv += ["--precision", precision]
-    args = M.parse_args(argv, make_dirs=False)
-    peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
-    gan = model.BigGAN(args, device="cuda", store=S.VariableStore("cuda", seed=42)).build_model()
-    real = gan.synthetic_batch(B)
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
     def note(msg):
         if rank == 0:
             print("[bench %7.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
-    if a.graph:
-        if world != 1:
-            raise SystemExit("--graph is a single-process option")
-        gan.capture_graphs(B)
-        a.no_roofline = True            # per-launch HIP events cannot be recorded inside a replayed graph
-    note("model built: %s%s" % (desc, " (HIP-graph replay)" if a.graph else ""))
-    for i in range(a.warmup):
-        gan.train_step(real)
-        torch.cuda.synchronize()
-        note("warmup step %d done" % i)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        losses = gan.train_step(real)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / a.steps * 1e3
-    value = B * world * a.steps / dt
-    note("timed %d steps: %.1f ms/step, %.1f images/sec" % (a.steps, ms_per_step, value))
+    default_run = a.workload == ""
+    name, B, scaling = resolve_workload(a.workload, world, a.scaling, a.batch)
+    img, ch, _, desc = WORKLOADS[name]
+    if a.graph and world != 1:
+        raise SystemExit("--graph is a single-process option (RCCL collectives cannot be captured on this stack: "
+                         "tools/rccl_graph_probe.py aborts)")
+    res = run_workload(name, B, a, world, rank, note, roofline=not a.no_roofline, graph=a.graph)
 
-    roof = None
-    if not a.no_roofline:
-        L = hip.lib()
-        L.bg_prof_reset()
-        L.bg_prof_enable(1)
-        nprof = min(a.steps, 3)
-        for _ in range(nprof):
-            gan.train_step(real)
-        torch.cuda.synchronize()
-        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-        L.bg_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
-        L.bg_prof_enable(0)
-        note("roofline pass done")
-        achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        fpi, fg, fd = step_flops_per_image(img, ch)
-        traffic, traffic_src = pmc_traffic(a.workload)
-        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-                "traffic_source": traffic_src,
-                "kernel": ("bg::nn16_kernel / bg::tn16_kernel (bf16-resident MFMA implicit GEMM: conv, deconv) + "
-                           "the fp32-tensor kernels for the image layers, dense layers and attention") if bf16 else
-                          "bg::nn_kernel / bg::tn_kernel (fp32 MFMA implicit GEMM: conv, deconv, dense) + bg::attn_* (fused attention)",
-                "launches_per_step": int(n.value // nprof), "gemm_ms_per_step": round(ms.value / nprof, 3),
-                "gemm_flops_per_step": fl.value / nprof,
-                "step_algorithmic_flops": fpi * B,
-                "step_frac_of_peak": round(fpi * B / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
+    target = None
+    if default_run and world == 1 and not a.no_target:
+        # BASELINE config 3 (the north-star target) at its global batch on this ONE GPU = the 1-GPU point of the
+        # strong-scaling curve, plus the two companions SURVEY 8(d) asks for
+        note("target: BASELINE config 3 (BigGAN-128 ch=96 bf16) at global batch 256 on one GPU ...")
+        t = run_workload("c3", 256, a, world, rank, note, steps=4, warmup=2, roofline=not a.no_roofline)
+        comp = {}
+        for key, extra in (("g_regularization_none", {"g_regularization": "none"}), ("da_policy_empty", {"da_policy": ""})):
+            c = run_workload("c3", 256, a, world, rank, note, extra=extra.items(), steps=3, warmup=1, roofline=False)
+            comp[key] = {"value": c["value"], "ms_per_step": c["ms_per_step"]}
+        per32 = run_workload("c3", 32, a, world, rank, note, steps=6, warmup=2, roofline=False)
+        target = {"metric": "BigGAN-128 ch=96 bf16 train-step images/sec (BASELINE config 3)", "n_gpus": 1,
+                  "value": t["value"], "unit": "images/sec", "ms_per_step": t["ms_per_step"], "global_batch": 256,
+                  "dtype": "bf16", "storage_dtype": t["storage_dtype"], "steps": t["steps"],
+                  "step_frac_of_peak": t["step_frac_of_peak"], "roofline": t.get("roofline"),
+                  "companions": comp, "losses": t["losses"],
+                  "per_gpu_share_32": {"value": per32["value"], "ms_per_step": per32["ms_per_step"],
+                                       "note": "one rank's work of the 8-GPU run (32 images per step), without collectives"}}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -265,20 +365,24 @@ def main():
         note("cpu baseline done")
 
     if rank == 0:
+        bf16 = name in BF16_WORKLOADS
         out = {
             "metric": "BigGAN-128 train-step images/sec" if img == 128 else "BigGAN-%d train-step images/sec" % img,
-            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "value": res["value"], "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": desc, "img_size": img, "ch": ch, "per_gpu_batch": B, "global_batch": B * world,
-                       "da_policy": a.da_policy, "g_regularization": a.g_regularization, "n_labels": a.n_labels, "gan_type": a.gan_type, "hip_graph": bool(a.graph), "precision": precision,
-                       "parallelism": "dp%d" % world},
-            "losses": {k: round(float(v.item()), 5) for k, v in losses.items()},
+                       "da_policy": a.da_policy, "g_regularization": a.g_regularization, "n_labels": a.n_labels,
+                       "gan_type": a.gan_type, "hip_graph": bool(a.graph), "precision": res["precision"],
+                       "storage_dtype": res["storage_dtype"], "parallelism": "dp%d" % world},
+            "losses": res["losses"],
         }
-        if roof is not None:
-            out["roofline"] = roof
+        if "roofline" in res:
+            out["roofline"] = res["roofline"]
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if target is not None:
+            out["target"] = target
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -1059,6 +1059,23 @@ class AddFn(Function):
         return dy, dy
 
 
+class GradMarkFn(Function):
+    """Identity whose backward calls ``callback(tag)``: when the engine reaches it, every node created AFTER it in the
+    forward pass has already run its backward (autograd runs ready nodes in reverse creation order), i.e. all layers
+    behind this point have final weight gradients.  Data parallelism uses it to start the gradient exchange of the
+    finished part of the network while the rest of backward is still running (model.BigGAN._g_bucket_done)."""
+
+    @staticmethod
+    def forward(ctx, x, callback, tag):
+        ctx.cb, ctx.tag = callback, tag
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ctx.cb(ctx.tag)
+        return dy, None, None
+
+
 class CastFn(Function):
     """Element-type conversion between the fp32 and the bf16 parts of a bf16-resident network (the image layers and
     the attention core stay fp32); the gradient is converted back."""

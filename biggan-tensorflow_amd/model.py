@@ -302,6 +302,7 @@ class BigGAN(GANBase):
 
             b_i = 0
             for block_count in counts:                                                 # BigGAN.py:449-489
+                x = self._grad_mark(x, 'resblock_up_' + str(ch_mul))
                 scope = 'resblock_up_' + str(ch_mul)
                 for sb_i in range(block_count):
                     layer_z, z_dim = next_z_split()
@@ -331,6 +332,7 @@ class BigGAN(GANBase):
                 ch = self.g_channels_for_block(b_i, len(counts))
                 ch_mul = ch_mul // 2
 
+            x = self._grad_mark(x, 'tail')
             x = ops._bn_act(x, None, opt, _out_fp32=True)                              # BigGAN.py:491-492
             x = conv(x, channels=self.c_dim, kernel=self.g_rgb_mix_kernel, stride=1, pad=1, use_bias=False, opt=opt,
                      scope='G_logit')                                                  # BigGAN.py:570
@@ -478,6 +480,52 @@ class BigGAN(GANBase):
         for b in getattr(self, "sn_batches", {}).get(group, ()):
             b.backward()
 
+    # ---- bucketed, overlapped exchange of the generator gradients (data parallel) -----------------------
+    def _g_bucket_starts(self):
+        """Arena offset at which the variables of each generator stage begin (stages in creation = arena order:
+        first/*, resblock_up_<m> ..., [self_attention], ..., tail = batch_norm / prelu / G_logit)."""
+        if getattr(self, "_g_starts", None) is None:
+            arena = self.g_arena
+            starts = {}
+            for name in arena.names:
+                off = arena.offsets[name][0]
+                rest = name[len("generator/"):]
+                top = rest.split("/")[0]
+                if top.startswith("resblock_up_"):
+                    key = "resblock_up_" + top[len("resblock_up_"):].split("_")[0]    # sub-blocks share their stage
+                elif top in ("batch_norm", "prelu", "G_logit"):
+                    key = "tail"
+                else:
+                    continue
+                starts[key] = min(starts.get(key, off), off)
+            self._g_starts = starts
+        return self._g_starts
+
+    def _grad_mark(self, x, tag):
+        st = getattr(self, "_g_overlap", None)
+        if st is None or not torch.is_grad_enabled() or not getattr(x, "requires_grad", False) or x.device.type != "cuda":
+            return x
+        return Fn.GradMarkFn.apply(x, self._g_bucket_done, tag)
+
+    def _g_bucket_done(self, tag):
+        """Backward has passed the input of stage ``tag``: every generator variable from that stage's first slot to the
+        last not-yet-exchanged slot has its final gradient.  Turn dL/d(w/sigma) into dL/dw for the newly finished
+        weights, zero what nothing wrote and start the asynchronous SUM all-reduce of that arena range."""
+        st = self._g_overlap
+        lo = self._g_bucket_starts().get(tag)
+        if st is None or lo is None or lo >= st["hi"]:
+            return
+        self._g_exchange_range(lo, st["hi"])
+        st["hi"] = lo
+
+    def _g_exchange_range(self, lo, hi):
+        from .parallel import allreduce_flat
+        st = self._g_overlap
+        self._sn_backward("generator")                      # (only the weights touched since the last call)
+        self.store.zero_untouched("generator", lo, hi)
+        works = allreduce_flat(self.g_arena.grads.narrow(0, lo, hi - lo), self.pg, async_op=True)
+        st["ranges"].append((lo, hi, works))
+
     # ---- data-parallel hooks -----------------------------------------------------------------
     def _reduce_fn(self):
         if self.world == 1:
@@ -503,13 +551,16 @@ class BigGAN(GANBase):
             arena.lr_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
         arena.lr_dev.fill_(lr_t)
 
-    def _adam(self, arena, lr, with_ema, grad_scale=1.0):
-        if not getattr(self, "_capturing", False):
+    def _adam(self, arena, lr, with_ema, grad_scale=1.0, lo=0, hi=None, prepare=True):
+        """TF-Adam (+ EMA) on the arena, or on its slice [lo, hi) (the optimiser is elementwise)."""
+        if prepare and not getattr(self, "_capturing", False):
             self._adam_prepare(arena, lr)          # (a captured graph is replayed after _adam_prepare on the host)
+        hi = arena.size if hi is None else hi
+        sl = (lambda t: t.narrow(0, lo, hi - lo)) if (lo, hi) != (0, arena.size) else (lambda t: t)
         hip.check(hip.lib().bg_adam_tf_ema_step_dev(
-            hip.f32(arena.params), hip.f32(arena.grads), hip.f32(arena.m), hip.f32(arena.v),
-            hip.f32(arena.ema) if with_ema else None, hip.f32(arena.lr_dev), self.beta1, self.beta2, 1e-8,
-            self.moving_decay, float(grad_scale), arena.size, hip.stream()))
+            hip.f32(sl(arena.params)), hip.f32(sl(arena.grads)), hip.f32(sl(arena.m)), hip.f32(sl(arena.v)),
+            hip.f32(sl(arena.ema)) if with_ema else None, hip.f32(arena.lr_dev), self.beta1, self.beta2, 1e-8,
+            self.moving_decay, float(grad_scale), hi - lo, hip.stream()))
 
     def sample_z(self, B):
         z = torch.empty(B, 1, 1, self.z_dim, dtype=torch.float32, device=self.device)
@@ -738,6 +789,9 @@ class BigGAN(GANBase):
         vb = self.virtual_batches
         self._set_requires_grad(self.d_vars, False)        # g_loss is minimised over g_vars only
         outs = []
+        # data parallel: exchange the generator gradients stage by stage while backward is still running
+        overlap = self.world > 1 and vb == 1 and self.device.type == "cuda" and not getattr(self, "_capturing", False)
+        self._g_overlap = {"hi": self.g_arena.size, "ranges": []} if overlap else None
         try:
             self.store.begin_backward("generator")
             for k in range(vb):
@@ -760,6 +814,21 @@ class BigGAN(GANBase):
                 outs.append(out)
         finally:
             self._set_requires_grad(self.d_vars, True)
+            st, self._g_overlap = getattr(self, "_g_overlap", None), None
+        if st is not None:
+            self._g_overlap = st
+            if st["hi"] > 0:
+                self._g_exchange_range(0, st["hi"])         # first/* (and anything no marker covered)
+            self._g_overlap = None
+            if apply:
+                self._adam_prepare(self.g_arena, self.g_learning_rate)
+            for lo, hi, works in st["ranges"]:              # in completion order: the last exchange overlaps the
+                for w in works:                             # optimiser of the earlier ranges
+                    w.wait()
+                if apply:
+                    self._adam(self.g_arena, self.g_learning_rate, with_ema=True, grad_scale=1.0, lo=lo, hi=hi,
+                               prepare=False)
+            return self._mean_losses(outs, ("g_adv", "g_reg", "g_loss", "g_cls_loss"))
         self.store.zero_untouched("generator")
         self._allreduce_grads(self.g_arena)
         if apply:

@@ -191,8 +191,13 @@ class VariableStore:
         for name in self.arenas[group].names:
             self.vars[name].bg_touched = False
 
-    def zero_untouched(self, group):
-        for name in self.arenas[group].names:
+    def zero_untouched(self, group, lo=0, hi=None):
+        """Zero the gradient slots no kernel wrote this step (optionally only the slots inside [lo, hi) of the arena)."""
+        arena = self.arenas[group]
+        for name in arena.names:
+            off = arena.offsets[name][0]
+            if off < lo or (hi is not None and off >= hi):
+                continue
             v = self.vars[name]
             if not v.bg_touched:
                 v.bg_grad.zero_()

@@ -451,3 +451,21 @@ def test_reference_names_of_the_boundary_exist_with_reference_signatures():
     import torch
     y = ops.global_avg_pooling(torch.empty(2, 4, 4, 8, device="meta"))
     assert tuple(y.shape) == (2, 8)
+
+
+def test_bench_keeps_the_global_batch_fixed_under_strong_scaling():
+    """bench.py --gpus N (SURVEY 8e, BASELINE config 3): the global batch stays 256 for N = 2, 4, 8 (strong scaling);
+    one GPU defaults to config 2; --scaling weak keeps 32 images per rank."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.resolve_workload("", 1) == ("c2", 64, "weak")
+    for n in (2, 4, 8):
+        name, b, mode = bench.resolve_workload("", n)
+        assert (name, mode) == ("c3", "strong") and b * n == 256
+    assert bench.resolve_workload("", 8, "weak") == ("c3", 32, "weak")
+    assert bench.resolve_workload("c5", 8) == ("c5", 64, "strong")
+    assert bench.resolve_workload("c2", 4) == ("c2", 64, "weak")
+    with pytest.raises(SystemExit):
+        bench.resolve_workload("c3", 3)
