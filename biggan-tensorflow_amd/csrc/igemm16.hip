@@ -47,6 +47,22 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_
     __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 
+// The same LDS-DMA in inline assembly (MI355X guide 5.7: M0 written in the statement that reads it).  hipcc does not
+// model it: it neither counts it in vmcnt nor knows that LDS is written, so the kernel owns the counted
+// s_waitcnt vmcnt(N) + barrier before the ds_reads of that tile - and the compiler does NOT drain the queue with a
+// vmcnt(0) in front of every ds_read that follows an LDS-DMA in program order, which it does for the builtin
+// (SIInsertWaitcnts treats an in-flight LDS-DMA as a store that any LDS read may alias).  That drain is what caps a
+// ring with more than one tile in flight; the 2-stage kernels, which wait for everything at their barrier anyway,
+// keep the builtin.  lds_byte_addr must be wave-uniform.
+__device__ __forceinline__ void glds16_asm(const void* src, uint32_t lds_byte_addr) {
+    unsigned keep;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(dst)
+                 : "memory");
+}
+
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     bf16x2_t v;
@@ -526,6 +542,166 @@ __global__ __launch_bounds__(256, 2) void tn16_kernel(const TN16Params p) {
 
 
 // ------------------------------------------------------------------------------------------
+// TN kernel, wide form: 256 x 128 tile, 8 waves, 3-stage LDS ring with counted vmcnt.
+//   The 128 x 128 kernel above keeps one 32 KB tile in flight per block (64 KB per CU) and moves 64 FLOP per loaded
+//   byte; measured (PMC, r02): 47 % of its wave cycles parked in s_waitcnt / barrier, MFMA busy 22 %, L2 -> LDS traffic
+//   6.9 TB/s - throughput = bytes in flight x FLOP per byte / latency.  Here a tile is 48 KB for 1.5x the FLOPs per byte
+//   (87), two tiles (96 KB) are in flight behind the one being computed, and the barrier no longer drains the queue:
+//   tile t + 2 is issued right after the barrier of iteration t, the wait before that barrier leaves tile t + 1 in
+//   flight (s_waitcnt vmcnt(6): 6 LDS-DMA instructions per wave and tile).  One block per CU (144 KB of LDS).
+// ------------------------------------------------------------------------------------------
+constexpr int TNX_STAGE = 3 * TN16_TILE;            // A image 0 | A image 1 | B image  (48 KB)
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void tn16x_kernel(const TN16Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 stages
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const Gather& g = p.g;
+
+    const int ntile = p.tiles_m * p.tiles_n;
+    const int lin = xcd_remap(blockIdx.x, ntile * p.splitk);
+    const int zs = lin / ntile;
+    const int tile = lin - zs * ntile;
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    const int mf0 = tile_m * 256, cb0 = tile_n * 128;
+    const int row_begin = zs * p.rows_per_split;
+    const int row_end = min(p.M, row_begin + p.rows_per_split);
+    const int nsteps = max(0, (row_end - row_begin + TN16_BK - 1) / TN16_BK);
+
+    // staging role: A image (w >> 2), pixel rows 16 j + 4 (w & 3) + prow (j = 0..3), channel chunk `ch` of that image;
+    // B: the same rows for j = 2 (w >> 2), 2 (w >> 2) + 1
+    const int prow = lane >> 4;
+    const int wq = w & 3, ia = w >> 2;
+    const int ch = (lane & 15) ^ ((prow << 2) | wq);
+    const int mf = mf0 + 128 * ia + 8 * ch;
+    int a_kh = 0, a_kw = 0, a_c = mf;
+    if (MODE != GATHER_PLAIN) {
+        const int tap = mf / p.Ca;
+        a_c = mf - tap * p.Ca;
+        a_kh = tap / g.k;
+        a_kw = tap - a_kh * g.k;
+    }
+    const bool a_ok = mf < p.Mf;
+    const int cb = cb0 + 8 * ch;
+    const bool b_ok = cb < p.Cb;
+    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
+    const __bf16* Bb = reinterpret_cast<const __bf16*>(p.Bv);
+    const void* zero = reinterpret_cast<const void*>(g_zero_page);
+    int m_next = row_begin + 4 * wq + prow;
+    const uint32_t lds0 = static_cast<uint32_t>(
+        reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem));
+
+    auto stage = [&](int slot) {
+        const uint32_t sa = lds0 + slot * TNX_STAGE + ia * TN16_TILE + (4 * wq) * 256;
+        const uint32_t sb = lds0 + slot * TNX_STAGE + 2 * TN16_TILE + (4 * wq) * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m_next + 16 * j;
+            const void* srca = zero;
+            if (m < row_end && a_ok) {
+                int64_t pix;
+                if (MODE == GATHER_PLAIN) {
+                    pix = m;
+                } else {
+                    int b, ho, wo;
+                    if (p.pow2) {
+                        wo = m & (g.Wq - 1);
+                        const int r = m >> p.wq_shift;
+                        ho = r & (g.Hq - 1);
+                        b = r >> p.hq_shift;
+                    } else {
+                        wo = m % g.Wq;
+                        const int r = m / g.Wq;
+                        ho = r % g.Hq;
+                        b = r / g.Hq;
+                    }
+                    const int hs = conv_src(ho, a_kh, g.stride, g.pad, g.reflect, g.Hs);
+                    const int ws = conv_src(wo, a_kw, g.stride, g.pad, g.reflect, g.Ws);
+                    pix = (hs >= 0 && ws >= 0) ? ((int64_t)b * g.Hs + hs) * g.Ws + ws : -1;
+                }
+                if (pix >= 0) srca = Ab + pix * g.ld + a_c;
+            }
+            glds16_asm(srca, sa + j * 16 * 256);
+            if ((j >> 1) == ia) {          // (wave-uniform) this wave's two rows of the B image
+                const void* srcb = (m < row_end && b_ok) ? static_cast<const void*>(Bb + (int64_t)m * p.b_ld + cb) : zero;
+                glds16_asm(srcb, sb + j * 16 * 256);
+            }
+        }
+        m_next += TN16_BK;
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kblk = lane >> 5, g16 = (lane >> 4) & 1, q = (lane & 15) >> 2, pq = lane & 3;
+    uint32_t a_ad[2][2], b_ad[2][2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int row = 8 * kblk + 4 * jj + q;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a_ad[i][jj] = lds0 + (wm >> 1) * TN16_TILE +
+                          tr16_swz(row, 4 * ((wm & 1) * 2 + i) + 2 * g16 + (pq >> 1)) + 8 * (pq & 1);
+            b_ad[i][jj] = lds0 + 2 * TN16_TILE + tr16_swz(row, 4 * (wn * 2 + i) + 2 * g16 + (pq >> 1)) + 8 * (pq & 1);
+        }
+    }
+    auto operand = [&](uint32_t lo_addr, uint32_t hi_addr) {
+        const s16x4v lo = lds_tr16(lo_addr), hi = lds_tr16(hi_addr);
+        const s16x8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8_t, v);
+    };
+
+    if (nsteps > 0) stage(0);
+    if (nsteps > 1) stage(1);
+    for (int it = 0; it < nsteps; ++it) {
+        // tile `it` has landed (this wave's part; the barrier extends that to every wave); tile it + 1 stays in flight
+        if (it + 1 < nsteps)
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + 2 < nsteps) stage((it + 2) % 3);        // the slot every wave finished reading before this barrier
+        const uint32_t bufoff = (uint32_t)(it % 3) * (uint32_t)TNX_STAGE;
+#pragma unroll
+        for (int s = 0; s < TN16_BK / 16; ++s) {
+            bf16x8_t a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = operand(a_ad[i][0] + bufoff + 4096 * s, a_ad[i][1] + bufoff + 4096 * s);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = operand(b_ad[j][0] + bufoff + 4096 * s, b_ad[j][1] + bufoff + 4096 * s);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    float* obase = p.out + (int64_t)zs * p.slab_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mf0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= p.Mf) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = cb0 + wn * 64 + 32 * j + (lane & 31);
+                if (col < p.Cb) obase[(int64_t)row * p.out_ld + col] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // transpose of tf.pad(REFLECT) (ops.py:82): fold the gradient on the padded grid back onto the image
 // ------------------------------------------------------------------------------------------
 template <bool F32>
@@ -741,10 +917,31 @@ static void plan_tn16(TN16Params& p) {
     p.rows_per_split = rps;
 }
 
+// wide form (tn16x_kernel): used when there are at least two 128-row tiles of output and the reduction fills the ring;
+// split so that the grid is a whole number of rounds of 256 co-resident blocks (one per CU)
+static bool plan_tn16x(const TN16Params& p, int* sk_out, int* rps_out) {
+    static const int use_wide = getenv("BG_TN16_WIDE") ? atoi(getenv("BG_TN16_WIDE")) : 1;
+    if (!use_wide || p.Mf <= 128 || p.M < 8 * TN16_BK) return false;
+    const int tm = (p.Mf + 255) / 256, tn = (p.Cb + 127) / 128;
+    static const int wantx = getenv("BG_TN16X_WANT") ? atoi(getenv("BG_TN16X_WANT")) : 512;
+    int sk = wantx / (tm * tn);
+    const int max_sk = (p.M + 4 * TN16_BK - 1) / (4 * TN16_BK);
+    if (sk > max_sk) sk = max_sk;
+    if (sk < 1) sk = 1;
+    if (sk > 512) sk = 512;
+    int rps = (p.M + sk - 1) / sk;
+    rps = (rps + TN16_BK - 1) / TN16_BK * TN16_BK;
+    *sk_out = (p.M + rps - 1) / rps;
+    *rps_out = rps;
+    return true;
+}
+
 size_t tn16_workspace_bytes(const TN16Params& p0) {
     TN16Params p = p0;
     plan_tn16(p);
-    return p.splitk > 1 ? (size_t)p.splitk * p.Mf * p.Cb * sizeof(float) : 0;
+    int sk = p.splitk, skx = 1, rps = 0;
+    if (plan_tn16x(p0, &skx, &rps) && skx > sk) sk = skx;
+    return sk > 1 ? (size_t)sk * p.Mf * p.Cb * sizeof(float) : 0;
 }
 
 int launch_tn16(TN16Params& p, int mode, float* final_out, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -772,6 +969,39 @@ int launch_tn16(TN16Params& p, int mode, float* final_out, void* ws, size_t ws_b
         p.pow2 = 1;
         p.wq_shift = __builtin_ctz(p.g.Wq);
         p.hq_shift = __builtin_ctz(p.g.Hq);
+    }
+    int sk = 1, rps = 0;
+    if (plan_tn16x(p, &sk, &rps)) {
+        const int tm = (p.Mf + 255) / 256, tn = (p.Cb + 127) / 128;
+        const bool can_split = ws != nullptr && ws_bytes >= (size_t)sk * total * sizeof(float) && p.out_ld == p.Cb;
+        if (sk == 1 || can_split) {
+            p.splitk = sk;
+            p.rows_per_split = rps;
+            p.out = sk > 1 ? reinterpret_cast<float*>(ws) : final_out;
+            p.slab_stride = sk > 1 ? total : 0;
+            p.tiles_m = tm;
+            p.tiles_n = tn;
+            constexpr int ldsx = 3 * TNX_STAGE;
+            static bool attr_x = false;
+            if (!attr_x) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16x_kernel<GATHER_CONV>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ldsx);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16x_kernel<GATHER_PLAIN>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ldsx);
+                attr_x = true;
+            }
+            dim3 gridx(tm * tn * sk, 1, 1);
+            if (mode == GATHER_CONV)
+                hipLaunchKernelGGL((tn16x_kernel<GATHER_CONV>), gridx, dim3(512), ldsx, s, p);
+            else
+                hipLaunchKernelGGL((tn16x_kernel<GATHER_PLAIN>), gridx, dim3(512), ldsx, s, p);
+            BG_LAUNCH_CHECK();
+            if (sk > 1) {
+                launch_slab_reduce(reinterpret_cast<const float*>(ws), final_out, total, sk, total, s);
+                BG_LAUNCH_CHECK();
+            }
+            return BG_OK;
+        }
     }
     dim3 grid(p.tiles_m * p.tiles_n * p.splitk, 1, 1);
     constexpr int lds = 4 * TN16_TILE;
