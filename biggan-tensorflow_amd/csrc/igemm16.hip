@@ -40,7 +40,7 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 typedef __attribute__((address_space(3))) s16x4v lds_s16x4v;
 
 // the source of every out-of-range 16-byte chunk (zero-initialised device memory of the code object)
-__device__ uint4 g_zero_page[4];
+__device__ uint4 g_zero_page[512];       // 8 KB: a gather row without a source reads zeros at any channel offset (C <= 4096)
 
 __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
     // LDS destination = wave-uniform base + lane * 16 ; the global source address is per lane
@@ -77,11 +77,14 @@ __device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast
 // NN kernel
 // ------------------------------------------------------------------------------------------
 constexpr int NN16_BM = 128;      // block tile rows; the K step is 64 bf16 = one 128-byte LDS row
+constexpr int NN16_TAPS = 4;      // taps per axis one block walks (kernel sizes 1, 3, 4)
+constexpr int NN16_TAB = 2 * NN16_TAPS * NN16_BM * 4;          // gather tables [axis][tap][row] of int32 behind the stages
 constexpr int nn16_lds_bytes(int TN) {
     const int stage = (NN16_BM + 32 * TN) * 128;
     const int epi = NN16_BM * (32 * TN + 4) * 4;
-    return 2 * stage > epi ? 2 * stage : epi;
+    return 2 * stage + NN16_TAB > epi ? 2 * stage + NN16_TAB : epi;
 }
+constexpr int NN16_NOSRC = -(1 << 30);                         // table entry of a tap without a source pixel
 
 // element offset of the source pixel of row r under tap (kh, kw), or -1 (selects, no divergent branches)
 template <int MODE>
@@ -159,58 +162,86 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
     const int it0 = zs * sps;
     const int nsteps = max(0, min(nsteps_all, it0 + sps) - it0);
 
+    // ---- gather tables ----
+    // The source pixel of (row, tap) separates into a row part and a column part: tabh[ih][row] = (b Hs + h) Ws and
+    // tabw[iw][row] = w (NN16_NOSRC where the tap has no source).  Built once per block; a tap change in the K walk
+    // then costs two LDS reads and an add per row instead of the whole gather arithmetic (which made the C = 96
+    // layers, where the tap changes every 1.5 K steps, VALU-bound at ~11 VALU instructions per MFMA).
+    int* tabh = reinterpret_cast<int*>(smem + 2 * STAGE);
+    int* tabw = tabh + NN16_TAPS * BM;
+    for (int e = t; e < 2 * NN16_TAPS * BM; e += 256) {
+        const int axis = e / (NN16_TAPS * BM), i = (e / BM) % NN16_TAPS, row = e % BM;
+        const RowPos r = nn16_row<MODE>(p, m0 + row, ph, pw);
+        int v = NN16_NOSRC;
+        if (r.valid && i < (axis ? nkw : nkh)) {
+            const int kk = (axis ? kw0 : kh0) + i * kstep;
+            const int o = axis ? r.wo : r.ho, n = axis ? g.Ws : g.Hs;
+            const int src = MODE == GATHER_CONV ? conv_src(o, kk, g.stride, g.pad, g.reflect, n)
+                                                : tconv_src_from_num(o + g.pad - kk, g.stride, n);
+            if (src >= 0) v = axis ? src : (r.b * g.Hs + src) * g.Ws;
+        }
+        tabh[e] = v;
+    }
+
     // ---- staging role of this lane: 16-byte chunk `cch` of the K step, rows 32 j + rsub of both tiles ----
     const int cch = (lane & 7) ^ ((((w & 1) << 2) | (lane >> 4)) & 7);
     const int rsub = 8 * w + (lane >> 3);
-    RowPos rows[JA];
-#pragma unroll
-    for (int j = 0; j < JA; ++j) rows[j] = nn16_row<MODE>(p, m0 + 32 * j + rsub, ph, pw);
-    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
-    const __bf16* Bb = reinterpret_cast<const __bf16*>(p.B);
-    const void* zero = reinterpret_cast<const void*>(g_zero_page);
+    const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.A);
+    const unsigned char* bbase = reinterpret_cast<const unsigned char*>(p.B);
+    const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero_page);
+    const unsigned ald2 = 2u * (unsigned)g.ld;
+    const uint32_t lds0 = static_cast<uint32_t>(
+        reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem));
 
-    int tidx, c8;
+    int tidx, c8, ih, iw;
     {
         const int kk = it0 * 8 + cch;
         tidx = kk / C8;
         c8 = kk - tidx * C8;
+        ih = tidx / nkw;
+        iw = tidx - ih * nkw;
     }
-    int64_t aoff[JA];
-    const __bf16* wtap = Bb;
+    const unsigned char* asrc[JA];       // source of this lane's chunk at channel 0 of the current tap (or the zero page)
+    const unsigned char* wsrc[JB];
     auto set_tap = [&]() {
-        if (tidx < ntap) {
-            const int ih = tidx / nkw, iw = tidx - ih * nkw;
-            const int kh = kh0 + ih * kstep, kw = kw0 + iw * kstep;
-#pragma unroll
-            for (int j = 0; j < JA; ++j) aoff[j] = nn16_src_off<MODE>(g, rows[j], kh, kw);
-            wtap = Bb + (int64_t)(kh * g.k + kw) * p.tap_stride;
-        } else {
-#pragma unroll
-            for (int j = 0; j < JA; ++j) aoff[j] = -1;
-        }
-    };
-    set_tap();
-
-    auto stage = [&](int buf) {
-        unsigned char* sa = smem + buf * STAGE + (8 * w) * 128;
-        unsigned char* sb = sa + A_BYTES;
         const bool kvalid = tidx < ntap;
+        const int* th = tabh + (ih & (NN16_TAPS - 1)) * BM + rsub;
+        const int* tw = tabw + (iw & (NN16_TAPS - 1)) * BM + rsub;
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
-            const void* src = aoff[j] >= 0 ? static_cast<const void*>(Ab + aoff[j] + c8 * 8) : zero;
-            glds16(src, sa + j * 32 * 128);
+            const int pix = th[32 * j] + tw[32 * j];
+            asrc[j] = (kvalid & (pix >= 0)) ? abase + (uint64_t)(unsigned)pix * ald2 : zero;
         }
+        const int kh = kh0 + ih * kstep, kw = kw0 + iw * kstep;
+        const unsigned char* wt = bbase + 2 * (int64_t)(kh * g.k + kw) * p.tap_stride;
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             const int n = n0 + 32 * j + rsub;
-            const void* src = (kvalid && n < p.N) ? static_cast<const void*>(wtap + (int64_t)n * p.C + c8 * 8) : zero;
-            glds16(src, sb + j * 32 * 128);
+            wsrc[j] = (kvalid & (n < p.N)) ? wt + 2 * (uint64_t)((unsigned)n * (unsigned)p.C) : zero;
         }
+    };
+    __syncthreads();                     // tables complete
+    set_tap();
+
+    // LDS-DMA through glds16_asm: the table reads of set_tap follow the DMA issue in program order, and behind the
+    // builtin the compiler would drain the queue (vmcnt(0)) in front of them; the wait before the barrier is explicit
+    auto stage = [&](int buf) {
+        const uint32_t sa = lds0 + buf * STAGE + (8 * w) * 128;
+        const uint32_t sb = sa + A_BYTES;
+        const unsigned cbyte = 16u * (unsigned)c8;
+#pragma unroll
+        for (int j = 0; j < JA; ++j) glds16_asm(asrc[j] + cbyte, sa + j * 32 * 128);
+#pragma unroll
+        for (int j = 0; j < JB; ++j) glds16_asm(wsrc[j] + cbyte, sb + j * 32 * 128);
         c8 += 8;
         if (c8 >= C8) {
             do {
                 c8 -= C8;
                 ++tidx;
+                if (++iw == nkw) {
+                    iw = 0;
+                    ++ih;
+                }
             } while (c8 >= C8);
             set_tap();
         }
@@ -233,7 +264,8 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
     for (int s2 = 0; s2 < 2; ++s2) koff[s2] = 16 * ((4 * s2 + (lane >> 4)) ^ fsw);
 
     if (nsteps > 0) stage(0);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
     for (int it = 0; it < nsteps; ++it) {
         const int cur = it & 1;
@@ -258,7 +290,9 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[s2][j], a[s2][i], acc[i][j], 0, 0, 0);
-        __syncthreads();
+        // the next tile has landed (this wave's part; the barrier extends it to all) and this one is read out
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
     // ---- epilogue: accumulators -> LDS [128][BN + 4] fp32 -> whole 16-byte row segments ----
@@ -584,15 +618,26 @@ __global__ __launch_bounds__(512, 2) void tn16x_kernel(const TN16Params p) {
         a_kh = tap / g.k;
         a_kw = tap - a_kh * g.k;
     }
-    const bool a_ok = mf < p.Mf;
     const int cb = cb0 + 8 * ch;
-    const bool b_ok = cb < p.Cb;
-    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
-    const __bf16* Bb = reinterpret_cast<const __bf16*>(p.Bv);
     const void* zero = reinterpret_cast<const void*>(g_zero_page);
     int m_next = row_begin + 4 * wq + prow;
     const uint32_t lds0 = static_cast<uint32_t>(
         reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem));
+
+    // The pixel row changes with every K step here (in the NN kernels it is fixed per block), so the row -> source
+    // address arithmetic is in the steady-state loop: straight-line integer code without divisions or branches
+    // (power-of-two pixel grid: plan_tn16x), about 25 VALU instructions per LDS-DMA.  The first form of this kernel
+    // reused the generic gather helpers and spent ~700 instructions per K step for 16 MFMAs - issue-bound at 23 %
+    // MFMA busy with the data already in LDS.
+    const int dh = a_kh - g.pad, dw = a_kw - g.pad;                   // tap displacement of this lane's channel chunk
+    const unsigned hmax = g.reflect ? 0xffffffffu : (unsigned)g.Hs - 1u;   // zero padding: out-of-range sources are zeros
+    const unsigned wmax = g.reflect ? 0xffffffffu : (unsigned)g.Ws - 1u;
+    const int h2 = 2 * (g.Hs - 1), w2 = 2 * (g.Ws - 1);
+    const int wmask = g.Wq - 1, hmask = g.Hq - 1, bsh = p.wq_shift + p.hq_shift;
+    const int a_lim = mf < p.Mf ? row_end : 0, b_lim = cb < p.Cb ? row_end : 0;
+    const unsigned char* abase = reinterpret_cast<const unsigned char*>(reinterpret_cast<const __bf16*>(p.A) + a_c);
+    const unsigned char* bbase = reinterpret_cast<const unsigned char*>(reinterpret_cast<const __bf16*>(p.Bv) + cb);
+    const unsigned ald2 = 2u * (unsigned)g.ld, bld2 = 2u * (unsigned)p.b_ld;
 
     auto stage = [&](int slot) {
         const uint32_t sa = lds0 + slot * TNX_STAGE + ia * TN16_TILE + (4 * wq) * 256;
@@ -600,33 +645,20 @@ __global__ __launch_bounds__(512, 2) void tn16x_kernel(const TN16Params p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m_next + 16 * j;
-            const void* srca = zero;
-            if (m < row_end && a_ok) {
-                int64_t pix;
-                if (MODE == GATHER_PLAIN) {
-                    pix = m;
-                } else {
-                    int b, ho, wo;
-                    if (p.pow2) {
-                        wo = m & (g.Wq - 1);
-                        const int r = m >> p.wq_shift;
-                        ho = r & (g.Hq - 1);
-                        b = r >> p.hq_shift;
-                    } else {
-                        wo = m % g.Wq;
-                        const int r = m / g.Wq;
-                        ho = r % g.Hq;
-                        b = r / g.Hq;
-                    }
-                    const int hs = conv_src(ho, a_kh, g.stride, g.pad, g.reflect, g.Hs);
-                    const int ws = conv_src(wo, a_kw, g.stride, g.pad, g.reflect, g.Ws);
-                    pix = (hs >= 0 && ws >= 0) ? ((int64_t)b * g.Hs + hs) * g.Ws + ws : -1;
-                }
-                if (pix >= 0) srca = Ab + pix * g.ld + a_c;
+            unsigned pix = (unsigned)m;
+            bool ok = m < a_lim;
+            if (MODE != GATHER_PLAIN) {
+                const int wo = m & wmask, ho = (m >> p.wq_shift) & hmask, b = m >> bsh;
+                const int h = __mul24(ho, g.stride) + dh, wsrc = __mul24(wo, g.stride) + dw;
+                const int ha = h < 0 ? -h : h, wa = wsrc < 0 ? -wsrc : wsrc;          // tf.pad(REFLECT): -1 -> 1, n -> n - 2
+                const int hr = min(ha, h2 - ha), wr = min(wa, w2 - wa);
+                ok = ok & ((unsigned)h <= hmax) & ((unsigned)wsrc <= wmax);
+                pix = __umul24(__umul24((unsigned)b, (unsigned)g.Hs) + (unsigned)hr, (unsigned)g.Ws) + (unsigned)wr;
             }
+            const void* srca = ok ? static_cast<const void*>(abase + (uint64_t)pix * ald2) : zero;
             glds16_asm(srca, sa + j * 16 * 256);
             if ((j >> 1) == ia) {          // (wave-uniform) this wave's two rows of the B image
-                const void* srcb = (m < row_end && b_ok) ? static_cast<const void*>(Bb + (int64_t)m * p.b_ld + cb) : zero;
+                const void* srcb = m < b_lim ? static_cast<const void*>(bbase + (uint64_t)(unsigned)m * bld2) : zero;
                 glds16_asm(srcb, sb + j * 16 * 256);
             }
         }
@@ -865,6 +897,9 @@ int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, 
     BG_REQUIRE((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(p.out) & 15) == 0,
                "bf16-resident conv: tensors must be 16-byte aligned");
+    BG_REQUIRE(p.g.k >= 1 && p.g.k <= NN16_TAPS && p.C <= 4096 && p.g.stride >= 1 && p.g.stride <= 2,
+               "bf16-resident conv: kernel size %d / stride %d / %d channels not supported", p.g.k, p.g.stride, p.C);
+    BG_REQUIRE((int64_t)p.g.Nb * p.g.Hs * p.g.Ws < (int64_t(1) << 30), "bf16-resident conv: more than 2^30 source pixels");
     NN16Plan pl = plan_nn16(p, mode, zdim, ws != nullptr);
     if (pl.splitk > 1 && ws_bytes < (size_t)pl.splitk * out_elems * sizeof(float)) pl.splitk = 1;
     p.splitk = pl.splitk;
@@ -922,6 +957,8 @@ static void plan_tn16(TN16Params& p) {
 static bool plan_tn16x(const TN16Params& p, int* sk_out, int* rps_out) {
     static const int use_wide = getenv("BG_TN16_WIDE") ? atoi(getenv("BG_TN16_WIDE")) : 1;
     if (!use_wide || p.Mf <= 128 || p.M < 8 * TN16_BK) return false;
+    // the kernel walks a power-of-two pixel grid by shifts (every BigGAN resolution is one); others take tn16_kernel
+    if (p.g.Wq <= 0 || p.g.Hq <= 0 || (p.g.Wq & (p.g.Wq - 1)) || (p.g.Hq & (p.g.Hq - 1))) return false;
     const int tm = (p.Mf + 255) / 256, tn = (p.Cb + 127) / 128;
     static const int wantx = getenv("BG_TN16X_WANT") ? atoi(getenv("BG_TN16X_WANT")) : 512;
     int sk = wantx / (tm * tn);

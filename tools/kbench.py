@@ -1,6 +1,6 @@
 """Per-layer kernel micro-benchmark through the C ABI.
 
-    python tools/kbench.py [filter] [fp32 | bf16-staged | bf16] [c2 | c3]
+    python tools/kbench.py [filter] [fp32 | bf16-staged | bf16] [c2 | c3] [batch multiplier]
 
 fp32 / bf16-staged: fp32 tensors (BgConvDesc.compute); bf16: the bf16-resident kernels (bf16 tensors + packed weights).
 Prints ms and TFLOP/s of the forward, input-gradient and weight-gradient launch of every layer shape of the chosen
@@ -60,14 +60,16 @@ def cases(cfg):
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 mode = sys.argv[2] if len(sys.argv) > 2 else "fp32"
 cfg = sys.argv[3] if len(sys.argv) > 3 else "c3"
+scale = int(sys.argv[4]) if len(sys.argv) > 4 else 1       # 8: config 3 at its global batch 256 on one GPU
 Fn.set_precision(mode)
 res = mode == "bf16"
 adt = torch.bfloat16 if res else torch.float32
 X, Y = (hip.BF16, hip.BF16) if res else (hip.F32, hip.F32)
-print("precision %s, config %s" % (mode, cfg))
+print("precision %s, config %s, batch x%d" % (mode, cfg, scale))
 print("%-44s %18s %18s %18s" % ("case", "fwd ms/TF", "dgrad ms/TF", "wgrad ms/TF"))
 tot = [0.0, 0.0, 0.0]
 for kind, N, H, Cin, Cout, k, s in cases(cfg):
+    N *= scale
     name = "%s N%d H%d %d->%d k%d s%d" % (kind, N, H, Cin, Cout, k, s)
     if flt and flt not in name:
         continue

@@ -10,5 +10,5 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLE
   echo "pass $n done"
 done
 cd $R
-python tools/summarize_pmc.py gpurun_out/pmc_${tag}.json gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE gpurun_out/pmc_${tag}_SQ_VALU_MFMA_BUSY_CYCLES > gpurun_out/pmc_${tag}.txt
+python tools/summarize_pmc.py gpurun_out/pmc_${tag}.json --iterations 3 gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE gpurun_out/pmc_${tag}_SQ_VALU_MFMA_BUSY_CYCLES > gpurun_out/pmc_${tag}.txt
 rm -rf gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE gpurun_out/pmc_${tag}_SQ_VALU_MFMA_BUSY_CYCLES

@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage (on the GPU box): tools/pmc_kbench.sh <tag> "<kbench filter>" [mode] [cfg]
+# usage (on the GPU box): tools/pmc_kbench.sh <tag> "<kbench filter>" [mode] [cfg] [batch multiplier]
 # PMC counters of the implicit-GEMM kernels on single layers (tools/kbench.py), one rocprofv3 --pmc pass per group
 # (SQ has 8 slots, TCC 4: MI355X_MICROARCH.md "rocprofv3 PMC slots"); summary -> gpurun_out/pmck_<tag>.txt
-tag=$1; flt=$2; mode=${3:-bf16}; cfg=${4:-c3}
+tag=$1; flt=$2; mode=${3:-bf16}; cfg=${4:-c3}; scale=${5:-1}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -11,7 +11,7 @@ for pass in "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS" \
             "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
             "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmck_${tag}_$i -o r -- python $R/tools/kbench.py "$flt" $mode $cfg > $R/gpurun_out/pmck_${tag}_$i.log 2>&1
+  timeout -k 10 150 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmck_${tag}_$i -o r -- python $R/tools/kbench.py "$flt" $mode $cfg $scale > $R/gpurun_out/pmck_${tag}_$i.log 2>&1
   echo "pass $i rc=$?"
 done
 cd $R

@@ -1,13 +1,17 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 --pmc counter_collection.csv files per kernel family.
 
-    python tools/summarize_pmc.py OUT.json DIR_OR_CSV [DIR_OR_CSV ...]
+    python tools/summarize_pmc.py OUT.json [--iterations N] DIR_OR_CSV [DIR_OR_CSV ...]
 
 Every pass (one directory per --pmc pass, see profiles/README.md) contributes its counters; per
 kernel family (name up to the first '<' / '(') the script reports launches, the mean of each
 counter per launch and, for FETCH_SIZE / WRITE_SIZE, bytes per launch with the corrections of
 MI355X_MICROARCH.md "HBM [CDNA4]": both counters are in KiB-like units of 1 KB (rocprofv3
 derived metric, KB), FETCH_SIZE on gfx950 reports half of a wide coalesced read and is doubled.
+Families that ran MFMA also get mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) (the guide's
+utilisation formula).  With --iterations N (training iterations inside the profiled command) the "_summary" entry
+holds the HBM bytes of the GEMM family (implicit-GEMM convolutions, their split-K / reflect folds, attention) per
+iteration.
 """
 import csv
 import json
@@ -23,8 +27,17 @@ def family(name):
     return m.group(1) if m else name[:80]
 
 
+GEMM_FAMILY = r"\b((nn|tn)(16x?)?_kernel|attn(16)?_|rgb_|thin_|slab_reduce|reflect_fold)"
+
+
 def main():
-    out, srcs = sys.argv[1], sys.argv[2:]
+    argv = sys.argv[1:]
+    iterations = 0
+    if "--iterations" in argv:
+        i = argv.index("--iterations")
+        iterations = int(argv[i + 1])
+        del argv[i:i + 2]
+    out, srcs = argv[0], argv[1:]
     files = []
     for s in srcs:
         if os.path.isdir(s):
@@ -61,9 +74,27 @@ def main():
         if "WRITE_SIZE" in agg[fam]:
             n, tot = agg[fam]["WRITE_SIZE"]
             e["hbm_write_bytes_per_launch"] = 1024.0 * tot / n
+        if agg[fam].get("SQ_VALU_MFMA_BUSY_CYCLES", [0, 0.0])[1] > 0 and "SQ_BUSY_CU_CYCLES" in agg[fam]:
+            e["mfma_busy"] = agg[fam]["SQ_VALU_MFMA_BUSY_CYCLES"][1] / (4.0 * agg[fam]["SQ_BUSY_CU_CYCLES"][1])
         res[fam] = e
+    if iterations:
+        rd = wr = us = 0.0
+        fams = []
+        for fam, e in res.items():
+            if re.search(GEMM_FAMILY, fam) and "hbm_read_bytes_per_launch" in e:
+                fams.append(fam)
+                rd += e["launches"] * e["hbm_read_bytes_per_launch"]
+                wr += e["launches"] * e.get("hbm_write_bytes_per_launch", 0.0)
+                us += e["launches"] * e["mean_us_under_pmc"]
+        res["_summary"] = OrderedDict(iterations=iterations, gemm_family_regex=GEMM_FAMILY, gemm_families=fams,
+                                      gemm_family_hbm_read_bytes_per_iteration=rd / iterations,
+                                      gemm_family_hbm_write_bytes_per_iteration=wr / iterations,
+                                      gemm_family_hbm_bytes_per_iteration=(rd + wr) / iterations,
+                                      gemm_family_us_per_iteration_under_pmc=us / iterations)
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
+    if "_summary" in res:
+        print("_summary", {k: v for k, v in res["_summary"].items() if k != "gemm_families"})
     for fam, e in list(res.items())[:40]:
         print("%-70s %s" % (fam[:70], {k: (round(v, 1) if isinstance(v, float) else v) for k, v in e.items()}))
 
