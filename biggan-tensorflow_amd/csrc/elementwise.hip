@@ -853,6 +853,37 @@ __device__ __forceinline__ void storev(__bf16* p, const float (&v)[VEC]) {
     }
 }
 
+// Widen or narrow the middle dimension of an [outer][C][inner] view (Cs -> Cd entries), converting the element type.
+//   mode 0  zero fill / truncate:  dst[c] = c < Cs ? src[c] : 0
+//   mode 1  split (Cd >= 2 Cs):    dst[c] = hi = bf16(src[c]),  dst[Cs + c] = src[c] - hi,  rest 0
+//   mode 2  duplicate (Cd >= 2 Cs): dst[c] = dst[Cs + c] = src[c],  rest 0
+//   mode 3  fold (Cs >= 2 Cd):     dst[c] = src[c] + src[Cd + c]
+// Modes 1-3 serve the 3-channel image layers of the bf16-resident path: the five padding channels a 3 -> 8 widening
+// leaves idle carry the bf16 rounding residual of the thin operand (image, image gradient, thin-side weights), so the
+// bf16 MFMA sees it to ~16 mantissa bits at no extra cost; the partner operand is duplicated, or the two partial
+// results are folded.
+template <class TS, class TD>
+__global__ __launch_bounds__(EW_BLOCK) void pad_channels_kernel(const TS* __restrict__ src, TD* __restrict__ dst,
+                                                                 int64_t total, int Cs, int Cd, int64_t inner, int mode) {
+    for (int64_t idx = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * EW_BLOCK) {
+        const int64_t i = idx % inner, t = idx / inner;
+        const int c = (int)(t % Cd);
+        const int64_t o = t / Cd;
+        const TS* sp = src + o * Cs * inner + i;
+        float v = 0.f;
+        if (mode == 3) {
+            v = (float)sp[(int64_t)c * inner] + (float)sp[(int64_t)(c + Cd) * inner];
+        } else if (c < Cs) {
+            v = (float)sp[(int64_t)c * inner];
+            if (mode == 1) v = (float)(__bf16)v;
+        } else if (mode != 0 && c < 2 * Cs) {
+            v = (float)sp[(int64_t)(c - Cs) * inner];
+            if (mode == 1) v -= (float)(__bf16)v;
+        }
+        dst[idx] = (TD)v;
+    }
+}
+
 template <class TX, class TY>
 __global__ __launch_bounds__(EW_BLOCK) void cast_kernel(const TX* __restrict__ x, TY* __restrict__ y, int64_t n) {
     const int64_t n4 = n / 4;
@@ -1230,10 +1261,21 @@ __device__ __forceinline__ void sn_rowdot_body(const float* __restrict__ w, cons
         const float* wr = w + (int64_t)r * cols;
         float s = 0.f;
         if ((cols & 3) == 0) {
-            for (int c = lane * 4; c < cols; c += 256) {
+            int c = lane * 4;
+            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (; c + 768 < cols; c += 1024) {          // four 16-byte loads of the row in flight per lane
+                const float4 a0 = ldg4(wr + c), a1 = ldg4(wr + c + 256), a2 = ldg4(wr + c + 512), a3 = ldg4(wr + c + 768);
+                const float4 b0 = ldg4(u + c), b1 = ldg4(u + c + 256), b2 = ldg4(u + c + 512), b3 = ldg4(u + c + 768);
+                s += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+                s1 += a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
+                s2 += a2.x * b2.x + a2.y * b2.y + a2.z * b2.z + a2.w * b2.w;
+                s3 += a3.x * b3.x + a3.y * b3.y + a3.z * b3.z + a3.w * b3.w;
+            }
+            for (; c < cols; c += 256) {
                 float4 a = ldg4(wr + c), b = ldg4(u + c);
                 s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
             }
+            s = (s + s1) + (s2 + s3);
         } else {
             for (int c = lane; c < cols; c += 64) s += wr[c] * u[c];
         }
@@ -1315,6 +1357,11 @@ __host__ __device__ inline void sn_colsum_plan(int rows, int cols, int* cblocks,
     *rpb = r;
     *rchunks = (rows + r - 1) / r;
 }
+// multi-tensor form: work units of 64 rows x 256 columns (64 KB), so that an item's share of the grid follows its size
+#define SN_COLSUM_RPB 64
+__device__ __forceinline__ int sn_colsum_units(int rows, int cols) {
+    return ((cols + EW_BLOCK - 1) / EW_BLOCK) * ((rows + SN_COLSUM_RPB - 1) / SN_COLSUM_RPB);
+}
 
 __global__ __launch_bounds__(EW_BLOCK) void sn_colsum_kernel(const float* __restrict__ w,
                                                               const float* __restrict__ vraw, double* uraw, int rows,
@@ -1391,22 +1438,69 @@ __device__ __forceinline__ double* sn_scr(const BgSnItem& it, char* ws) {
     return reinterpret_cast<double*>(ws + it.ws_offset);
 }
 
-__global__ __launch_bounds__(EW_BLOCK) void sn_batch_rowdot_kernel(const BgSnItem* __restrict__ items, char* ws) {
-    const BgSnItem it = items[blockIdx.y];
-    double* scr = sn_scr(it, ws);
-    float* vraw = reinterpret_cast<float*>(scr + 4 + it.cols);
-    sn_rowdot_body(it.w, it.u, vraw, scr, it.rows, it.cols, blockIdx.x, gridDim.x);
+// Work schedule of the multi-tensor kernels.  One launch covers every spectrally normalised weight of a network: 3 KB
+// biases-of-biases up to 150 MB transposed-conv kernels.  With blockIdx.y = item and a fixed number of blocks per item
+// the few big weights - all of the bytes - ran on 128 blocks each with one load in flight per wave (measured r02:
+// 0.8 - 1.5 TB/s).  Here the grid is flat: every block derives the same table of work units per item (units follow the
+// item's size, `kind` says how) and strides over the units.
+#define SN_GRID 2048
+#define SN_UNIT_ELEMS 16384          // 64 KB of fp32 per streaming unit
+#define SN_UNIT_ELEMS_REDUCE 262144  // 1 MB per unit where every unit ends in an atomic on ONE address of its item
+                                     // (same-address atomics retire at ~10 M/s: 2304 of them cost more than the pass)
+__device__ __forceinline__ int sn_units_of(const BgSnItem& it, int kind) {
+    const int64_t n = (int64_t)it.rows * it.cols;
+    if (kind == 1) return sn_colsum_units(it.rows, it.cols);
+    const int64_t per = kind == 2 ? SN_UNIT_ELEMS / 2 : kind == 3 ? SN_UNIT_ELEMS_REDUCE : SN_UNIT_ELEMS;
+    const int64_t u = (n + per - 1) / per;
+    return u < 1 ? 1 : (int)u;
+}
+// start[i] .. start[i + 1] = units of item i; returns the total
+__device__ __forceinline__ int sn_sched_build(int* start, const BgSnItem* __restrict__ items, int n_items, int kind,
+                                              const SnMask* enable) {
+    for (int i = threadIdx.x; i < n_items; i += EW_BLOCK)
+        start[i + 1] = (enable && !sn_bit(*enable, i)) ? 0 : sn_units_of(items[i], kind);
+    if (threadIdx.x == 0) start[0] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int i = 1; i <= n_items; ++i) start[i] += start[i - 1];
+    __syncthreads();
+    return start[n_items];
+}
+__device__ __forceinline__ int sn_sched_find(const int* start, int n_items, int unit) {
+    int lo = 0, hi = n_items;            // largest i with start[i] <= unit
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (start[mid] <= unit) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 
-__global__ __launch_bounds__(EW_BLOCK) void sn_batch_colsum_kernel(const BgSnItem* __restrict__ items, char* ws) {
-    const BgSnItem it = items[blockIdx.y];
-    double* scr = sn_scr(it, ws);
-    float* vraw = reinterpret_cast<float*>(scr + 4 + it.cols);
-    int cblocks, rpb, rchunks;
-    sn_colsum_plan(it.rows, it.cols, &cblocks, &rpb, &rchunks);
-    const int units = cblocks * rchunks;
-    for (int unit = blockIdx.x; unit < units; unit += gridDim.x)
-        sn_colsum_body(it.w, vraw, scr + 4, it.rows, it.cols, rpb, unit % cblocks, unit / cblocks);
+__global__ __launch_bounds__(EW_BLOCK) void sn_batch_rowdot_kernel(const BgSnItem* __restrict__ items, int n_items,
+                                                                    char* ws) {
+    __shared__ int start[257];
+    const int total = sn_sched_build(start, items, n_items, 3, nullptr);
+    for (int unit = blockIdx.x; unit < total; unit += gridDim.x) {
+        const int j = sn_sched_find(start, n_items, unit);
+        const BgSnItem it = items[j];
+        double* scr = sn_scr(it, ws);
+        float* vraw = reinterpret_cast<float*>(scr + 4 + it.cols);
+        sn_rowdot_body(it.w, it.u, vraw, scr, it.rows, it.cols, unit - start[j], start[j + 1] - start[j]);
+    }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void sn_batch_colsum_kernel(const BgSnItem* __restrict__ items, int n_items,
+                                                                    char* ws) {
+    __shared__ int start[257];
+    const int total = sn_sched_build(start, items, n_items, 1, nullptr);
+    for (int unit = blockIdx.x; unit < total; unit += gridDim.x) {
+        const int j = sn_sched_find(start, n_items, unit);
+        const BgSnItem it = items[j];
+        double* scr = sn_scr(it, ws);
+        float* vraw = reinterpret_cast<float*>(scr + 4 + it.cols);
+        const int cblocks = (it.cols + EW_BLOCK - 1) / EW_BLOCK;
+        const int u = unit - start[j];
+        sn_colsum_body(it.w, vraw, scr + 4, it.rows, it.cols, SN_COLSUM_RPB, u % cblocks, u / cblocks);
+    }
 }
 
 __global__ __launch_bounds__(EW_BLOCK) void sn_batch_finalize_kernel(const BgSnItem* __restrict__ items, char* ws) {
@@ -1416,57 +1510,86 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_batch_finalize_kernel(const BgSnI
     sn_finalize_body(scr, scr + 4, it.u, it.sigma, it.cols, sh);
 }
 
-__global__ __launch_bounds__(EW_BLOCK) void sn_batch_normalize_kernel(const BgSnItem* __restrict__ items, char* ws) {
+__global__ __launch_bounds__(EW_BLOCK) void sn_batch_normalize_kernel(const BgSnItem* __restrict__ items, int n_items,
+                                                                       char* ws) {
     __shared__ float tile[64][65];
-    const BgSnItem it = items[blockIdx.y];
-    double* scr = sn_scr(it, ws);
-    const float* vraw = reinterpret_cast<const float*>(scr + 4 + it.cols);
-    if (it.pack_p) {
-        // conv / transposed-conv kernel of the bf16-resident path: w / sigma in fp32 plus the two bf16 packed copies
-        sn_normalize_pack_body(it.w, (float)scr[1], it.w_norm, reinterpret_cast<__bf16*>(it.pack_p),
-                               reinterpret_cast<__bf16*>(it.pack_t), it.taps, it.rows / it.taps, it.cols,
-                               it.pack_p_ld > 0 ? it.pack_p_ld : it.cols, blockIdx.x, gridDim.x, tile);
-        const float rs_v = (float)scr[2];
-        for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < it.rows; i += (int64_t)gridDim.x * EW_BLOCK)
-            it.v[i] = vraw[i] * rs_v;
-        return;
+    __shared__ int start[257];
+    const int total = sn_sched_build(start, items, n_items, 2, nullptr);
+    for (int unit = blockIdx.x; unit < total; unit += gridDim.x) {
+        const int j = sn_sched_find(start, n_items, unit);
+        const BgSnItem it = items[j];
+        const int bid = unit - start[j], nb = start[j + 1] - start[j];
+        double* scr = sn_scr(it, ws);
+        const float* vraw = reinterpret_cast<const float*>(scr + 4 + it.cols);
+        if (it.pack_p) {
+            // conv / transposed-conv kernel of the bf16-resident path: w / sigma in fp32 plus the two bf16 packed copies
+            sn_normalize_pack_body(it.w, (float)scr[1], it.w_norm, reinterpret_cast<__bf16*>(it.pack_p),
+                                   reinterpret_cast<__bf16*>(it.pack_t), it.taps, it.rows / it.taps, it.cols,
+                                   it.pack_p_ld > 0 ? it.pack_p_ld : it.cols, bid, nb, tile);
+            const float rs_v = (float)scr[2];
+            for (int64_t i = (int64_t)bid * EW_BLOCK + threadIdx.x; i < it.rows; i += (int64_t)nb * EW_BLOCK)
+                it.v[i] = vraw[i] * rs_v;
+            continue;
+        }
+        sn_normalize_body(it.w, scr, vraw, it.w_norm, it.v, (int64_t)it.rows * it.cols, it.rows, bid, nb);
     }
-    sn_normalize_body(it.w, scr, vraw, it.w_norm, it.v, (int64_t)it.rows * it.cols, it.rows, blockIdx.x, gridDim.x);
 }
 
 // dots[item] = <g_wnorm, w_norm>
-__global__ __launch_bounds__(EW_BLOCK) void sn_batch_dot_kernel(const BgSnItem* __restrict__ items, double* dots,
-                                                                 SnMask enable) {
+__global__ __launch_bounds__(EW_BLOCK) void sn_batch_dot_kernel(const BgSnItem* __restrict__ items, int n_items,
+                                                                 double* dots, SnMask enable) {
     __shared__ float sh[4];
-    if (!sn_bit(enable, blockIdx.y)) return;
-    const BgSnItem it = items[blockIdx.y];
-    const int64_t n = (int64_t)it.rows * it.cols;
-    const int64_t n4 = n / 4;
-    if ((int64_t)blockIdx.x * EW_BLOCK >= n4 + (n - n4 * 4)) return;
-    float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
-        float4 av = ldg4(it.g_wnorm + i * 4), bv = ldg4(it.w_norm + i * 4);
-        s += av.x * bv.x + av.y * bv.y + av.z * bv.z + av.w * bv.w;
+    __shared__ int start[257];
+    const int total = sn_sched_build(start, items, n_items, 3, &enable);
+    for (int unit = blockIdx.x; unit < total; unit += gridDim.x) {
+        const int j = sn_sched_find(start, n_items, unit);
+        const BgSnItem it = items[j];
+        const int bid = unit - start[j], nb = start[j + 1] - start[j];
+        const int64_t n = (int64_t)it.rows * it.cols;
+        const int64_t n4 = n / 4;
+        float s = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const int64_t step = (int64_t)nb * EW_BLOCK;
+        int64_t i = (int64_t)bid * EW_BLOCK + threadIdx.x;
+        for (; i + 3 * step < n4; i += 4 * step) {          // eight 16-byte loads in flight per thread
+            const float4 a0 = ldg4(it.g_wnorm + i * 4), b0 = ldg4(it.w_norm + i * 4);
+            const float4 a1 = ldg4(it.g_wnorm + (i + step) * 4), b1 = ldg4(it.w_norm + (i + step) * 4);
+            const float4 a2 = ldg4(it.g_wnorm + (i + 2 * step) * 4), b2 = ldg4(it.w_norm + (i + 2 * step) * 4);
+            const float4 a3 = ldg4(it.g_wnorm + (i + 3 * step) * 4), b3 = ldg4(it.w_norm + (i + 3 * step) * 4);
+            s += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+            s1 += a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
+            s2 += a2.x * b2.x + a2.y * b2.y + a2.z * b2.z + a2.w * b2.w;
+            s3 += a3.x * b3.x + a3.y * b3.y + a3.z * b3.z + a3.w * b3.w;
+        }
+        for (; i < n4; i += step) {
+            float4 av = ldg4(it.g_wnorm + i * 4), bv = ldg4(it.w_norm + i * 4);
+            s += av.x * bv.x + av.y * bv.y + av.z * bv.z + av.w * bv.w;
+        }
+        s = (s + s1) + (s2 + s3);
+        for (int64_t t = n4 * 4 + (int64_t)bid * EW_BLOCK + threadIdx.x; t < n; t += step)
+            s += it.g_wnorm[t] * it.w_norm[t];
+        __syncthreads();                 // sh is reused across units
+        s = block_sum_256(s, sh);
+        if (threadIdx.x == 0) atomicAdd(&dots[j], (double)s);
     }
-    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK)
-        s += it.g_wnorm[i] * it.w_norm[i];
-    s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) atomicAdd(&dots[blockIdx.y], (double)s);
 }
 
 // dw (+)= (g - dot * v^T u) / sigma
-__global__ __launch_bounds__(EW_BLOCK) void sn_batch_bwd_kernel(const BgSnItem* __restrict__ items, const double* dots,
-                                                                 SnMask enable, SnMask accumulate) {
-    if (!sn_bit(enable, blockIdx.y)) return;
-    const BgSnItem it = items[blockIdx.y];
-    const bool acc = sn_bit(accumulate, blockIdx.y);
+__global__ __launch_bounds__(EW_BLOCK) void sn_batch_bwd_kernel(const BgSnItem* __restrict__ items, int n_items,
+                                                                 const double* dots, SnMask enable, SnMask accumulate) {
+    __shared__ int start[257];
+    const int total = sn_sched_build(start, items, n_items, 0, &enable);
+    for (int unit = blockIdx.x; unit < total; unit += gridDim.x) {
+    const int j = sn_sched_find(start, n_items, unit);
+    const BgSnItem it = items[j];
+    const int bid = unit - start[j], nb = start[j + 1] - start[j];
+    const bool acc = sn_bit(accumulate, j);
     const float inv_sigma = 1.f / *it.sigma;
-    const float d = (float)dots[blockIdx.y];
+    const float d = (float)dots[j];
     const int cols = it.cols;
     const int64_t n = (int64_t)it.rows * cols;
     if ((cols & 3) == 0) {
         const int64_t n4 = n / 4;
-        for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_BLOCK) {
+        for (int64_t i = (int64_t)bid * EW_BLOCK + threadIdx.x; i < n4; i += (int64_t)nb * EW_BLOCK) {
             const int64_t e = i * 4;
             const int r = (int)(e / cols), c = (int)(e - (int64_t)r * cols);
             const float4 g = ldg4(it.g_wnorm + e), u = ldg4(it.u + c);
@@ -1480,11 +1603,12 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_batch_bwd_kernel(const BgSnItem* 
             stg4(it.dw + e, o);
         }
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_BLOCK) {
+        for (int64_t i = (int64_t)bid * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)nb * EW_BLOCK) {
             const int r = (int)(i / cols), c = (int)(i % cols);
             const float o = (it.g_wnorm[i] - d * it.v[r] * it.u[c]) * inv_sigma;
             it.dw[i] = acc ? it.dw[i] + o : o;
         }
+    }
     }
 }
 
@@ -1951,15 +2075,14 @@ int bg_spectral_norm_batch_fwd(const BgSnItem* items_dev, int n_items, void* ws,
         return BG_ERR_LAUNCH;
     }
     char* w8 = reinterpret_cast<char*>(ws);
-    const int GX = 128;
-    hipLaunchKernelGGL(sn_batch_rowdot_kernel, dim3(GX, n_items), dim3(EW_BLOCK), 0, s, items_dev, w8);
+    BG_REQUIRE(n_items <= 256, "bg_spectral_norm_batch_fwd: 1..256 items per call");
+    hipLaunchKernelGGL(sn_batch_rowdot_kernel, dim3(SN_GRID), dim3(EW_BLOCK), 0, s, items_dev, n_items, w8);
     BG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sn_batch_colsum_kernel, dim3(GX, n_items), dim3(EW_BLOCK), 0, s, items_dev, w8);
+    hipLaunchKernelGGL(sn_batch_colsum_kernel, dim3(SN_GRID), dim3(EW_BLOCK), 0, s, items_dev, n_items, w8);
     BG_LAUNCH_CHECK();
     hipLaunchKernelGGL(sn_batch_finalize_kernel, dim3(n_items), dim3(EW_BLOCK), 0, s, items_dev, w8);
     BG_LAUNCH_CHECK();
-    // streaming pass: the largest kernels (85 MB at ch = 96) need more than 128 blocks to pull full bandwidth
-    hipLaunchKernelGGL(sn_batch_normalize_kernel, dim3(4 * GX, n_items), dim3(EW_BLOCK), 0, s, items_dev, w8);
+    hipLaunchKernelGGL(sn_batch_normalize_kernel, dim3(SN_GRID), dim3(EW_BLOCK), 0, s, items_dev, n_items, w8);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }
@@ -1978,9 +2101,9 @@ int bg_spectral_norm_batch_bwd(const BgSnItem* items_dev, int n_items, const uin
         return BG_ERR_LAUNCH;
     }
     double* dots = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL(sn_batch_dot_kernel, dim3(256, n_items), dim3(EW_BLOCK), 0, s, items_dev, dots, en);
+    hipLaunchKernelGGL(sn_batch_dot_kernel, dim3(SN_GRID), dim3(EW_BLOCK), 0, s, items_dev, n_items, dots, en);
     BG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sn_batch_bwd_kernel, dim3(512, n_items), dim3(EW_BLOCK), 0, s, items_dev, dots, en, acc);
+    hipLaunchKernelGGL(sn_batch_bwd_kernel, dim3(SN_GRID), dim3(EW_BLOCK), 0, s, items_dev, n_items, dots, en, acc);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }
@@ -2033,6 +2156,20 @@ int bg_cast(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, void* s
     BG_DISPATCH_XY(x_dtype, y_dtype,
                    hipLaunchKernelGGL((cast_kernel<TX, TY>), dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, as_stream(stream),
                                       (const TX*)x, (TY*)y, n));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_pad_channels(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t outer, int Cs, int Cd, int64_t inner,
+                    int mode, void* stream) {
+    BG_REQUIRE(src && dst && outer > 0 && Cs > 0 && Cd > 0 && inner > 0 && BG_DT_OK(src_dtype) && BG_DT_OK(dst_dtype),
+               "bg_pad_channels: bad argument");
+    BG_REQUIRE(mode == 0 || ((mode == 1 || mode == 2) && Cd >= 2 * Cs) || (mode == 3 && Cs >= 2 * Cd),
+               "bg_pad_channels: mode %d does not fit %d -> %d channels", mode, Cs, Cd);
+    const int64_t total = outer * Cd * inner;
+    BG_DISPATCH_XY(src_dtype, dst_dtype,
+                   hipLaunchKernelGGL((pad_channels_kernel<TX, TY>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0,
+                                      as_stream(stream), (const TX*)src, (TY*)dst, total, Cs, Cd, inner, mode));
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

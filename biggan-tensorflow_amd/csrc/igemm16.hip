@@ -26,6 +26,7 @@
 #include "common.h"
 #include "igemm.h"
 #include "igemm16.h"
+#include <type_traits>
 #include "igemm_dev.h"
 
 namespace bg {
@@ -82,7 +83,7 @@ constexpr int NN16_TAB = 2 * NN16_TAPS * NN16_BM * 4;          // gather tables 
 constexpr int nn16_lds_bytes(int TN) {
     const int stage = (NN16_BM + 32 * TN) * 128;
     const int epi = NN16_BM * (32 * TN + 4) * 4;
-    return 2 * stage + NN16_TAB > epi ? 2 * stage + NN16_TAB : epi;
+    return (2 * stage + NN16_TAB > epi ? 2 * stage + NN16_TAB : epi) + NN16_BM * 4;   // + output pixel of every row
 }
 constexpr int NN16_NOSRC = -(1 << 30);                         // table entry of a tap without a source pixel
 
@@ -181,6 +182,13 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
             if (src >= 0) v = axis ? src : (r.b * g.Hs + src) * g.Ws;
         }
         tabh[e] = v;
+    }
+    // output pixel of every row (transposed gathers: rows enumerate a stride phase, possibly of a padded grid), behind
+    // everything the epilogue overlays; 0xffffffff = no output
+    unsigned* tabo = reinterpret_cast<unsigned*>(smem + nn16_lds_bytes(TN) - BM * 4);
+    if (MODE == GATHER_TCONV && t < BM) {
+        const RowPos r = nn16_row<MODE>(p, m0 + t, ph, pw);
+        tabo[t] = (r.valid && r.ho < g.Ho && r.wo < g.Wo) ? (unsigned)((r.b * g.Ho + r.ho) * g.Wo + r.wo) : 0xffffffffu;
     }
 
     // ---- staging role of this lane: 16-byte chunk `cch` of the K step, rows 32 j + rsub of both tiles ----
@@ -321,9 +329,9 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
         if (m >= p.M || col >= p.N) continue;
         int64_t ooff;
         if (MODE == GATHER_TCONV) {
-            const RowPos rp = nn16_row<MODE>(p, m, ph, pw);
-            if (rp.ho >= g.Ho || rp.wo >= g.Wo) continue;
-            ooff = (((int64_t)rp.b * g.Ho + rp.ho) * g.Wo + rp.wo) * p.out_ld + col;
+            const unsigned op = tabo[row];
+            if (op == 0xffffffffu) continue;
+            ooff = (int64_t)op * p.out_ld + col;
         } else {
             ooff = (int64_t)m * p.out_ld + col;
         }
@@ -639,9 +647,12 @@ __global__ __launch_bounds__(512, 2) void tn16x_kernel(const TN16Params p) {
     const unsigned char* bbase = reinterpret_cast<const unsigned char*>(reinterpret_cast<const __bf16*>(p.Bv) + cb);
     const unsigned ald2 = 2u * (unsigned)g.ld, bld2 = 2u * (unsigned)p.b_ld;
 
+    // wave-uniform LDS destinations as scalars (SALU adds per LDS-DMA instead of VALU + readfirstlane)
+    const uint32_t sa0 = __builtin_amdgcn_readfirstlane(lds0 + ia * TN16_TILE + (4 * wq) * 256);
+    const uint32_t sb0 = __builtin_amdgcn_readfirstlane(lds0 + 2 * TN16_TILE + (4 * wq) * 256);
     auto stage = [&](int slot) {
-        const uint32_t sa = lds0 + slot * TNX_STAGE + ia * TN16_TILE + (4 * wq) * 256;
-        const uint32_t sb = lds0 + slot * TNX_STAGE + 2 * TN16_TILE + (4 * wq) * 256;
+        const uint32_t sa = sa0 + slot * TNX_STAGE;
+        const uint32_t sb = sb0 + slot * TNX_STAGE;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m_next + 16 * j;
@@ -693,28 +704,35 @@ __global__ __launch_bounds__(512, 2) void tn16x_kernel(const TN16Params p) {
 
     if (nsteps > 0) stage(0);
     if (nsteps > 1) stage(1);
-    for (int it = 0; it < nsteps; ++it) {
+    // one K step on ring slot SLOT (a compile-time constant: the operand addresses are base + immediate)
+    auto kstep = [&](int it, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
         // tile `it` has landed (this wave's part; the barrier extends that to every wave); tile it + 1 stays in flight
         if (it + 1 < nsteps)
             asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (it + 2 < nsteps) stage((it + 2) % 3);        // the slot every wave finished reading before this barrier
-        const uint32_t bufoff = (uint32_t)(it % 3) * (uint32_t)TNX_STAGE;
+        if (it + 2 < nsteps) stage((SLOT + 2) % 3);      // the slot every wave finished reading before this barrier
+        constexpr uint32_t bufoff = (uint32_t)SLOT * (uint32_t)TNX_STAGE;
 #pragma unroll
         for (int s = 0; s < TN16_BK / 16; ++s) {
             bf16x8_t a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = operand(a_ad[i][0] + bufoff + 4096 * s, a_ad[i][1] + bufoff + 4096 * s);
+            for (int i = 0; i < 2; ++i) a[i] = operand(a_ad[i][0] + (bufoff + 4096 * s), a_ad[i][1] + (bufoff + 4096 * s));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = operand(b_ad[j][0] + bufoff + 4096 * s, b_ad[j][1] + bufoff + 4096 * s);
+            for (int j = 0; j < 2; ++j) b[j] = operand(b_ad[j][0] + (bufoff + 4096 * s), b_ad[j][1] + (bufoff + 4096 * s));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+    };
+    for (int it = 0; it < nsteps; it += 3) {
+        kstep(it, std::integral_constant<int, 0>());
+        if (it + 1 < nsteps) kstep(it + 1, std::integral_constant<int, 1>());
+        if (it + 2 < nsteps) kstep(it + 2, std::integral_constant<int, 2>());
     }
 
     float* obase = p.out + (int64_t)zs * p.slab_stride;
@@ -899,7 +917,8 @@ int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, 
                "bf16-resident conv: tensors must be 16-byte aligned");
     BG_REQUIRE(p.g.k >= 1 && p.g.k <= NN16_TAPS && p.C <= 4096 && p.g.stride >= 1 && p.g.stride <= 2,
                "bf16-resident conv: kernel size %d / stride %d / %d channels not supported", p.g.k, p.g.stride, p.C);
-    BG_REQUIRE((int64_t)p.g.Nb * p.g.Hs * p.g.Ws < (int64_t(1) << 30), "bf16-resident conv: more than 2^30 source pixels");
+    BG_REQUIRE((int64_t)p.g.Nb * p.g.Hs * p.g.Ws < (int64_t(1) << 30) && (int64_t)p.g.Nb * p.g.Ho * p.g.Wo < (int64_t(1) << 31),
+               "bf16-resident conv: more than 2^30 source / 2^31 output pixels");
     NN16Plan pl = plan_nn16(p, mode, zdim, ws != nullptr);
     if (pl.splitk > 1 && ws_bytes < (size_t)pl.splitk * out_elems * sizeof(float)) pl.splitk = 1;
     p.splitk = pl.splitk;

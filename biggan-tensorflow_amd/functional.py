@@ -5,6 +5,9 @@ operation is a libbiggan_hip.so launch on the current stream.  Gradients of stor
 written straight into their slice of the flat gradient arena (``scope.Arena``) instead of
 ``Tensor.grad``: the first write of a step overwrites, later ones accumulate.
 """
+import math
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -164,6 +167,34 @@ def _resident_ok(x, cin, cout):
     return x.dtype == BF16 and cin % 8 == 0 and cout % 8 == 0
 
 
+def pad_channels(x, C, dtype, axis=-1, mode=hip.PAD_ZERO_FILL):
+    """Copy of ``x`` with dimension ``axis`` widened or narrowed to C entries, converted to ``dtype``
+    (``mode``: zero fill / split into bf16 value + rounding residual / duplicate / fold two halves: bg_pad_channels)."""
+    x = _c(x)
+    axis = axis % x.dim()
+    shape = list(x.shape)
+    outer = int(math.prod(shape[:axis])) if axis else 1
+    inner = int(math.prod(shape[axis + 1:])) if axis + 1 < len(shape) else 1
+    Cs = shape[axis]
+    shape[axis] = C
+    y = torch.empty(shape, dtype=dtype, device=x.device)
+    check(lib().bg_pad_channels(act(x), dt(x), act(y), dt(y), outer, Cs, C, inner, mode, stream()))
+    return y
+
+
+def _thin_plan(x, cin, cout):
+    """bf16-resident mode, the 3-channel image layers (D's first block: Cin = 3; G_logit: Cout = 3): run on the
+    bf16-resident GEMM kernels with the thin side zero-padded to 8 channels.  The fp32-tensor fallbacks they replace
+    cost 16.8 of 137 ms per config-3 iteration at batch 256 (r02 kernel stats) for 0.3 % of the FLOPs."""
+    if not Precision.resident or x.dtype not in (BF16, torch.float32) or os.environ.get("BG_IMAGE_LAYERS", "") == "fp32":
+        return None                      # (BG_IMAGE_LAYERS=fp32: A/B switch, the fp32-tensor kernels of round 1)
+    if cin < 8 and cout % 8 == 0:
+        return "in"
+    if cout < 8 and cin % 8 == 0 and x.dtype == BF16:
+        return "out"
+    return None
+
+
 class Conv2dFn(Function):
     """tf.pad(REFLECT)+tf.nn.conv2d(VALID)+bias_add (ops.py:82,94-98) / zero 'SAME'.
 
@@ -185,8 +216,36 @@ class Conv2dFn(Function):
         L = lib()
         ctx.resident = _resident_ok(x, Cin, Cout)
         ctx.in_dtype = x.dtype
+        ctx.pad8 = None if ctx.resident else _thin_plan(x, Cin, Cout)
+        if ctx.pad8 == "in":
+            # x8 = [x_hi | x_lo | 0 0]: the image to ~16 mantissa bits in the otherwise idle padding channels;
+            # forward and wgrad pair it with the kernel duplicated over the two groups of rows
+            x8 = pad_channels(x, 8, BF16, mode=hip.PAD_SPLIT)
+            ydt = out_dtype or BF16
+            d = hip.conv_desc(N, H, W_, 8, Ho, Wo, Cout, k, stride, pad_lo, pad_mode, hip.COMPUTE_BF16, hip.BF16,
+                              hip.BF16 if ydt == BF16 else hip.F32, 1)
+            y = torch.empty((N, Ho, Wo, Cout), dtype=ydt, device=x.device)
+            ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, d, x.device)
+            pt = weight_packs(pad_channels(w, 8, torch.float32, axis=2, mode=hip.PAD_DUP))[1]
+            check(L.bg_conv2d_fwd(d, act(x8), act(pt), f32(bias), None, act(y), 0, f32(ws), nb, stream()))
+            ctx.desc, ctx.rgb, ctx.thin = d, False, False
+            ctx.x, ctx.w, ctx.bias = x8, w, bias
+            return y
+        if ctx.pad8 == "out":
+            # w8 = [w_hi | w_lo | 0 0] along the output channels: y = y8[:3] + y8[3:6] sees the kernel to ~16 bits
+            b8 = None if bias is None else pad_channels(bias, 8, torch.float32)
+            ydt = out_dtype or torch.float32
+            d = hip.conv_desc(N, H, W_, Cin, Ho, Wo, 8, k, stride, pad_lo, pad_mode, hip.COMPUTE_BF16, hip.BF16,
+                              hip.F32, 1)
+            y8 = torch.empty((N, Ho, Wo, 8), dtype=torch.float32, device=x.device)
+            ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, d, x.device)
+            pt = weight_packs(pad_channels(w, 8, torch.float32, axis=3, mode=hip.PAD_SPLIT))[1]
+            check(L.bg_conv2d_fwd(d, act(x), act(pt), f32(b8), None, act(y8), 0, f32(ws), nb, stream()))
+            ctx.desc, ctx.rgb, ctx.thin = d, False, False
+            ctx.x, ctx.w, ctx.bias = x, w, bias
+            return pad_channels(y8, Cout, ydt, mode=hip.PAD_FOLD)
         if x.dtype == BF16 and not ctx.resident:
-            x = cast(x, torch.float32)         # (odd channel counts / the 3-channel head: fp32-tensor kernels)
+            x = cast(x, torch.float32)         # (odd channel counts: fp32-tensor kernels)
         if ctx.resident:
             ydt = out_dtype or BF16
             d = hip.conv_desc(N, H, W_, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode, hip.COMPUTE_BF16, hip.BF16,
@@ -220,6 +279,46 @@ class Conv2dFn(Function):
         L = lib()
         dx = None
         db = None
+        if ctx.pad8:
+            Cin, Cout = w.shape[2], w.shape[3]
+            thin_in = ctx.pad8 == "in"
+            if bias is not None:
+                db = param_grad(bias, ctx.needs_input_grad[2], lambda out: _bias_grad(dy.view(-1, Cout), out))
+            # thin output: dy8 = [dy_hi | dy_lo | 0 0] - the gradient of the generated image, the 3-channel bottleneck
+            # every generator gradient passes through, enters the GEMMs to ~16 bits
+            dy8 = cast(dy, BF16) if thin_in else pad_channels(dy, 8, BF16, mode=hip.PAD_SPLIT)
+            db16 = hip.conv_desc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.k, d.stride, d.pad_lo, d.pad_mode,
+                                 hip.COMPUTE_BF16, hip.BF16, hip.BF16, 1)
+            if ctx.needs_input_grad[0]:
+                if thin_in:
+                    # kernel rows [w_hi | w_lo]: dx = dx8[:3] + dx8[3:6], written by an fp32 epilogue (image gradient)
+                    pp = weight_packs(pad_channels(w, 8, torch.float32, axis=2, mode=hip.PAD_SPLIT))[0]
+                    dd = hip.conv_desc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.k, d.stride, d.pad_lo, d.pad_mode,
+                                       hip.COMPUTE_BF16, hip.F32, hip.BF16, 1)
+                    dx8 = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+                else:
+                    pp = weight_packs(pad_channels(w, 8, torch.float32, axis=3, mode=hip.PAD_DUP))[0]
+                    dd = db16
+                    dx8 = torch.empty_like(x)
+                ws, nb = hip.scratch(L.bg_conv2d_dgrad_workspace_bytes, dd, x.device)
+                check(L.bg_conv2d_dgrad(dd, act(dy8), act(pp), None, act(dx8), 0, f32(ws), nb, stream()))
+                dx = pad_channels(dx8, Cin, ctx.in_dtype, mode=hip.PAD_FOLD) if thin_in else dx8
+
+            def wg8(out):
+                # x8 = [x_hi | x_lo] (thin input) or dy8 = [dy_hi | dy_lo] (thin output): dw = the two halves folded
+                nb = L.bg_conv2d_wgrad_workspace_bytes(db16)
+                ws = workspace(nb, x.device)
+                dw8 = torch.empty((d.k, d.k, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
+                check(L.bg_conv2d_wgrad(db16, act(x), act(dy8), f32(dw8), f32(ws), nb, stream()))
+                if thin_in:
+                    check(L.bg_pad_channels(act(dw8), hip.F32, act(out), hip.F32, d.k * d.k, 8, Cin, d.Cout,
+                                            hip.PAD_FOLD, stream()))
+                else:
+                    check(L.bg_pad_channels(act(dw8), hip.F32, act(out), hip.F32, d.k * d.k * d.Cin, 8, Cout, 1,
+                                            hip.PAD_FOLD, stream()))
+            dw = param_grad(w, ctx.needs_input_grad[1], wg8)
+            ctx.x = ctx.w = ctx.bias = None
+            return dx, dw, db, None, None, None, None, None, None
         if bias is not None:
             db = param_grad(bias, ctx.needs_input_grad[2], lambda out: _bias_grad(dy.view(-1, d.Cout), out))
         if ctx.resident:

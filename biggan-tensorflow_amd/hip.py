@@ -16,6 +16,7 @@ ABI_VERSION = 2
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 PAD_REFLECT, PAD_ZERO = 0, 1
+PAD_ZERO_FILL, PAD_SPLIT, PAD_DUP, PAD_FOLD = 0, 1, 2, 3      # bg_pad_channels modes
 F32, BF16 = 0, 1                       # BG_F32 / BG_BF16: element types of activation tensors
 COMPUTE_F32, COMPUTE_BF16 = 0, 1       # per-call arithmetic of the GEMM-shaped launches
 
@@ -147,6 +148,7 @@ SIGNATURES = {
     "bg_adam_tf_ema_step_dev": (c_int, [_P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int64,
                                         _P]),
     "bg_cast": (c_int, [_P, c_int, _P, c_int, c_int64, _P]),
+    "bg_pad_channels": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, c_int64, c_int, _P]),
     "bg_weight_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "bg_bn_stats_t": (c_int, [_P, c_int, _P, c_int64, c_int, _P]),
     "bg_bn_apply_act_fwd_t": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),

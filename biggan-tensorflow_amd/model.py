@@ -333,7 +333,7 @@ class BigGAN(GANBase):
                 ch_mul = ch_mul // 2
 
             x = self._grad_mark(x, 'tail')
-            x = ops._bn_act(x, None, opt, _out_fp32=True)                              # BigGAN.py:491-492
+            x = ops._bn_act(x, None, opt, _out_fp32=os.environ.get("BG_IMAGE_LAYERS", "") == "fp32")   # BigGAN.py:491-492
             x = conv(x, channels=self.c_dim, kernel=self.g_rgb_mix_kernel, stride=1, pad=1, use_bias=False, opt=opt,
                      scope='G_logit')                                                  # BigGAN.py:570
             x = tanh(x)                                                                # BigGAN.py:580

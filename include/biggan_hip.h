@@ -332,6 +332,15 @@ int bg_bias_grad(const float* dy, float* db, int64_t rows, int C, void* stream);
  * fp32 entry points of the same name.
  * ------------------------------------------------------------------------------------------ */
 int bg_cast(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, void* stream);
+/* Widen or narrow the middle dimension of an [outer][C][inner] view from Cs to Cd entries, converting between fp32 and
+ * bf16: the 3-channel image layers (ops.py:49 with Cin = 3, BigGAN.py:570 with Cout = 3) run on the bf16-resident GEMMs
+ * with the thin side widened to 8 channels.  mode BG_PAD_ZERO_FILL (0): dst[c] = c < Cs ? src[c] : 0;
+ * BG_PAD_SPLIT (1, Cd >= 2 Cs): dst[c] = bf16(src[c]), dst[Cs + c] = src[c] - bf16(src[c]) - the idle padding channels
+ * carry the rounding residual, so the MFMA sees the thin operand to ~16 mantissa bits; BG_PAD_DUP (2): dst[c] =
+ * dst[Cs + c] = src[c] (the partner operand of a split one); BG_PAD_FOLD (3, Cs >= 2 Cd): dst[c] = src[c] + src[Cd + c]. */
+enum { BG_PAD_ZERO_FILL = 0, BG_PAD_SPLIT = 1, BG_PAD_DUP = 2, BG_PAD_FOLD = 3 };
+int bg_pad_channels(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t outer, int Cs, int Cd,
+                    int64_t inner, int mode, void* stream);
 /* the two packed bf16 copies of a conv kernel that is NOT spectrally normalised (see BgSnItem::pack_p / pack_t) */
 int bg_weight_pack(const float* w, int taps, int rows_per_tap, int cols, void* pack_p, void* pack_t, void* stream);
 int bg_bn_stats_t(const void* x, int x_dtype, double* sums, int64_t rows, int C, void* stream);
