@@ -86,7 +86,9 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(Fn fn, OutT* out, i
     }
 }
 
-template <int NQ, class Fn, class OutT>
+// WIDE: 8 columns per thread when C % 8 == 0 - the 16-byte loads of a bf16 tensor (4 columns would be 8-byte loads and
+// half the bytes in flight the block counts below were tuned for)
+template <int NQ, bool WIDE = false, class Fn, class OutT>
 static void launch_colreduce(Fn fn, OutT* out, int64_t qstride, int64_t rows_per_seg, int nseg, int C,
                              hipStream_t s) {
     // Every block ends with one atomic per column on the SAME addresses, and those serialise (~0.1 us per
@@ -100,6 +102,13 @@ static void launch_colreduce(Fn fn, OutT* out, int64_t qstride, int64_t rows_per
     if (rpb < 32) rpb = 32;
     blocks_per_seg = (rows_per_seg + rpb - 1) / rpb;
     dim3 grid((unsigned)blocks_per_seg, (unsigned)nseg);
+    if constexpr (WIDE) {
+        if (C % 8 == 0) {
+            hipLaunchKernelGGL((colreduce_kernel<NQ, 8, Fn, OutT>), grid, dim3(EW_BLOCK), 0, s, fn, out, qstride,
+                               rows_per_seg, C, (int)rpb);
+            return;
+        }
+    }
     if (C % 4 == 0)
         hipLaunchKernelGGL((colreduce_kernel<NQ, 4, Fn, OutT>), grid, dim3(EW_BLOCK), 0, s, fn, out, qstride, rows_per_seg,
                            C, (int)rpb);
@@ -116,6 +125,10 @@ __device__ __forceinline__ void loadv(const float* p, float (&v)[VEC]) {
         v[1] = t.y;
         v[2] = t.z;
         v[VEC - 1] = t.w;
+    } else if constexpr (VEC == 8) {
+        const float4 a = ldg4(p), b = ldg4(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[VEC - 1] = b.w;
     } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v[j] = p[j];
@@ -819,6 +832,12 @@ __device__ __forceinline__ void loadv(const __bf16* p, float (&v)[VEC]) {
         v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
         v[2] = __builtin_bit_cast(float, r.y << 16);
         v[VEC - 1] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+    } else if constexpr (VEC == 8) {
+        const uint4 r = *reinterpret_cast<const uint4*>(p);
+        v[0] = __builtin_bit_cast(float, r.x << 16); v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+        v[2] = __builtin_bit_cast(float, r.y << 16); v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+        v[4] = __builtin_bit_cast(float, r.z << 16); v[5] = __builtin_bit_cast(float, r.z & 0xffff0000u);
+        v[6] = __builtin_bit_cast(float, r.w << 16); v[VEC - 1] = __builtin_bit_cast(float, r.w & 0xffff0000u);
     } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v[j] = (float)p[j];
@@ -942,6 +961,112 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_fwd_t_kernel(const TX* 
         }
         storev<VEC>(y + i * VEC, out);
     }
+}
+
+// ---- bf16 fast forms of batch-norm apply (+PReLU) and its input gradient --------------------------------------
+// The generic kernels above spend two 64-bit divisions and five to nine 16-byte coefficient loads per 8 bytes of
+// activation (measured r02: 2.9 - 3.3 TB/s of tensor traffic, ~10 % of a config-3 iteration).  Here a thread keeps ONE
+// group of 8 channels for its whole walk - the grid stride is a multiple of C / 8 - so the per-channel coefficients
+// sit in registers (reloaded only when a conditional batch norm moves to the next sample) and an item is one 16-byte
+// load, 8 FMAs + PReLU, one 16-byte store.
+__device__ __forceinline__ void bf16x8_load(const __bf16* p, float (&v)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    v[0] = __builtin_bit_cast(float, r.x << 16); v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, r.y << 16); v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+    v[4] = __builtin_bit_cast(float, r.z << 16); v[5] = __builtin_bit_cast(float, r.z & 0xffff0000u);
+    v[6] = __builtin_bit_cast(float, r.w << 16); v[7] = __builtin_bit_cast(float, r.w & 0xffff0000u);
+}
+__device__ __forceinline__ void bf16x8_store(__bf16* p, const float (&v)[8]) {
+    uint4 r;
+    r.x = bf16_pack2(v[0], v[1]); r.y = bf16_pack2(v[2], v[3]); r.z = bf16_pack2(v[4], v[5]); r.w = bf16_pack2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = r;
+}
+__device__ __forceinline__ void f32x8_load(const float* p, float (&v)[8]) {
+    const float4 a = ldg4(p), b = ldg4(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// rows = N * HW pixels of C = 8 CV channels; (gridDim.x * EW_BLOCK) % CV == 0
+__global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_fwd_bf16x8_kernel(
+    const __bf16* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int per_sample, const float* __restrict__ alpha,
+    __bf16* __restrict__ y, int rows, int HW, int CV) {
+    const int gtid = blockIdx.x * EW_BLOCK + threadIdx.x;
+    const int cv = gtid % CV, c = cv * 8, C = CV * 8;
+    const int rstep = (gridDim.x * EW_BLOCK) / CV;
+    float mu[8], rs[8], al[8], inv[8], sh[8];
+    f32x8_load(mean + c, mu);
+    f32x8_load(rstd + c, rs);
+    if (alpha) f32x8_load(alpha + c, al);
+    int r_end = 0;                       // rows [.., r_end) share the coefficients in registers
+    for (int r = gtid / CV; r < rows; r += rstep) {
+        if (r >= r_end) {
+            const int n = per_sample ? r / HW : 0;
+            r_end = per_sample ? (n + 1) * HW : rows;
+            float ga[8], be[8];
+            f32x8_load(gamma + (int64_t)n * C * per_sample + c, ga);
+            f32x8_load(beta + (int64_t)n * C * per_sample + c, be);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                inv[j] = rs[j] * ga[j];
+                sh[j] = be[j] - mu[j] * inv[j];
+            }
+        }
+        float xv[8], out[8];
+        bf16x8_load(x + (int64_t)r * C + c, xv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = xv[j] * inv[j] + sh[j];
+            out[j] = alpha ? prelu_f(v, al[j]) : v;
+        }
+        bf16x8_store(y + (int64_t)r * C + c, out);
+    }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_bwd_dx_bf16x8_kernel(
+    const __bf16* __restrict__ x, const __bf16* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta, int per_sample,
+    const float* __restrict__ alpha, const float* __restrict__ cm, __bf16* __restrict__ dx, int rows, int HW, int CV) {
+    const int gtid = blockIdx.x * EW_BLOCK + threadIdx.x;
+    const int cv = gtid % CV, c = cv * 8, C = CV * 8;
+    const int rstep = (gridDim.x * EW_BLOCK) / CV;
+    float mu[8], rs[8], al[8], m1[8], m2[8], ga[8], be[8];
+    f32x8_load(mean + c, mu);
+    f32x8_load(rstd + c, rs);
+    f32x8_load(cm + c, m1);
+    f32x8_load(cm + C + c, m2);
+    if (alpha) f32x8_load(alpha + c, al);
+    int r_end = 0;
+    for (int r = gtid / CV; r < rows; r += rstep) {
+        if (r >= r_end) {
+            const int n = per_sample ? r / HW : 0;
+            r_end = per_sample ? (n + 1) * HW : rows;
+            f32x8_load(gamma + (int64_t)n * C * per_sample + c, ga);
+            f32x8_load(beta + (int64_t)n * C * per_sample + c, be);
+        }
+        float xv[8], dv[8], out[8];
+        bf16x8_load(x + (int64_t)r * C + c, xv);
+        bf16x8_load(dy + (int64_t)r * C + c, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (xv[j] - mu[j]) * rs[j];
+            const float pre = xh * ga[j] + be[j];
+            const float g = alpha ? dv[j] * prelu_d(pre, al[j]) : dv[j];
+            out[j] = rs[j] * (g * ga[j] - m1[j] - xh * m2[j]);
+        }
+        bf16x8_store(dx + (int64_t)r * C + c, out);
+    }
+}
+
+// grid for the x8 kernels: enough blocks to fill the chip, a multiple of CV / gcd(CV, EW_BLOCK)
+static inline int bn_x8_grid(int64_t rows, int CV) {
+    int a = CV, b = EW_BLOCK;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int unit = CV / a;
+    int64_t want = (rows * CV + EW_BLOCK - 1) / EW_BLOCK;
+    if (want > 4096) want = 4096;
+    if (want < 1) want = 1;
+    return (int)((want + unit - 1) / unit * unit);
 }
 
 template <class TX, class TY>
@@ -1257,37 +1382,45 @@ __device__ __forceinline__ void sn_rowdot_body(const float* __restrict__ w, cons
     const int wave = bid * 4 + (threadIdx.x >> 6);
     const int nwaves = nblocks * 4;
     double ss = 0.0;
-    for (int r = wave; r < rows; r += nwaves) {
-        const float* wr = w + (int64_t)r * cols;
-        float s = 0.f;
-        if ((cols & 3) == 0) {
-            int c = lane * 4;
-            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (; c + 768 < cols; c += 1024) {          // four 16-byte loads of the row in flight per lane
-                const float4 a0 = ldg4(wr + c), a1 = ldg4(wr + c + 256), a2 = ldg4(wr + c + 512), a3 = ldg4(wr + c + 768);
-                const float4 b0 = ldg4(u + c), b1 = ldg4(u + c + 256), b2 = ldg4(u + c + 512), b3 = ldg4(u + c + 768);
-                s += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
-                s1 += a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
-                s2 += a2.x * b2.x + a2.y * b2.y + a2.z * b2.z + a2.w * b2.w;
-                s3 += a3.x * b3.x + a3.y * b3.y + a3.z * b3.z + a3.w * b3.w;
-            }
-            for (; c < cols; c += 256) {
-                float4 a = ldg4(wr + c), b = ldg4(u + c);
-                s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-            }
-            s = (s + s1) + (s2 + s3);
-        } else {
-            for (int c = lane; c < cols; c += 64) s += wr[c] * u[c];
+    // four rows per wave at a time: four independent 16-byte loads in flight per lane whatever the row length (a wave
+    // walking ONE row of 768 floats has a single 1 KB load in flight per round trip: measured 1.9 TB/s over a network)
+    for (int r0 = wave; r0 < rows; r0 += 4 * nwaves) {
+        const float* wr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rk = r0 + k * nwaves;
+            wr[k] = w + (int64_t)(rk < rows ? rk : r0) * cols;
         }
-        s = wave_sum(s);
-        if (lane == 0) {
-            vraw[r] = s;
-            ss += (double)s * (double)s;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((cols & 3) == 0) {
+            for (int c = lane * 4; c < cols; c += 256) {
+                const float4 b = ldg4(u + c);
+                float4 a[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = ldg4(wr[k] + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += a[k].x * b.x + a[k].y * b.y + a[k].z * b.z + a[k].w * b.w;
+            }
+        } else {
+            for (int c = lane; c < cols; c += 64) {
+                const float b = u[c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += wr[k][c] * b;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = wave_sum(s[k]);
+            const int rk = r0 + k * nwaves;
+            if (lane == 0 && rk < rows) {
+                vraw[rk] = t;
+                ss += (double)t * (double)t;
+            }
         }
     }
     // fp64 accumulation: the sum is the same to ~1e-16 whatever the arrival order of the waves, so
     // the forward pass is reproducible from run to run
-    if (lane == 0 && ss != 0.0) atomicAdd(ssv, ss);
+    if (ssv && lane == 0 && ss != 0.0) atomicAdd(ssv, ss);      // (multi-tensor form: ssv == nullptr, see its finalize)
 }
 
 __global__ __launch_bounds__(EW_BLOCK) void sn_rowdot_kernel(const float* __restrict__ w,
@@ -1478,13 +1611,15 @@ __device__ __forceinline__ int sn_sched_find(const int* start, int n_items, int 
 __global__ __launch_bounds__(EW_BLOCK) void sn_batch_rowdot_kernel(const BgSnItem* __restrict__ items, int n_items,
                                                                     char* ws) {
     __shared__ int start[257];
-    const int total = sn_sched_build(start, items, n_items, 3, nullptr);
+    // 64 KB units and NO atomic: sum v_^2 is taken from v_ itself by the item's finalize block (a same-address atomic
+    // per wave capped this pass at 1.9 TB/s with 1 MB units, and at 1.2 TB/s with small ones)
+    const int total = sn_sched_build(start, items, n_items, 0, nullptr);
     for (int unit = blockIdx.x; unit < total; unit += gridDim.x) {
         const int j = sn_sched_find(start, n_items, unit);
         const BgSnItem it = items[j];
         double* scr = sn_scr(it, ws);
         float* vraw = reinterpret_cast<float*>(scr + 4 + it.cols);
-        sn_rowdot_body(it.w, it.u, vraw, scr, it.rows, it.cols, unit - start[j], start[j + 1] - start[j]);
+        sn_rowdot_body(it.w, it.u, vraw, nullptr, it.rows, it.cols, unit - start[j], start[j + 1] - start[j]);
     }
 }
 
@@ -1507,6 +1642,12 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_batch_finalize_kernel(const BgSnI
     __shared__ float sh[4];
     const BgSnItem it = items[blockIdx.x];
     double* scr = sn_scr(it, ws);
+    const float* vraw = reinterpret_cast<const float*>(scr + 4 + it.cols);
+    double ssd = 0.0;
+    for (int r = threadIdx.x; r < it.rows; r += EW_BLOCK) ssd += (double)vraw[r] * (double)vraw[r];
+    const float ss = block_sum_256((float)ssd, sh);
+    if (threadIdx.x == 0) scr[0] = (double)ss;
+    __syncthreads();
     sn_finalize_body(scr, scr + 4, it.u, it.sigma, it.cols, sh);
 }
 
@@ -2187,7 +2328,7 @@ int bg_weight_pack(const float* w, int taps, int rows_per_tap, int cols, void* p
 int bg_bn_stats_t(const void* x, int x_dtype, double* sums, int64_t rows, int C, void* stream) {
     BG_REQUIRE(x && sums && rows > 0 && C > 0 && BG_DT_OK(x_dtype), "bg_bn_stats_t: bad argument");
     BG_DISPATCH_T(x_dtype, BnStatsFnT<T> fn{(const T*)x, C};
-                  launch_colreduce<2>(fn, sums, (int64_t)C, rows, 1, C, as_stream(stream)));
+                  launch_colreduce<2, sizeof(T) == 2>(fn, sums, (int64_t)C, rows, 1, C, as_stream(stream)));
     BG_LAUNCH_CHECK();
     return BG_OK;
 }
@@ -2198,6 +2339,14 @@ int bg_bn_apply_act_fwd_t(const void* x, int x_dtype, const float* mean, const f
     BG_REQUIRE(x && mean && rstd && gamma && beta && y && N > 0 && HW > 0 && C > 0 && BG_DT_OK(x_dtype) && BG_DT_OK(y_dtype),
                "bg_bn_apply_act_fwd_t: bad argument");
     const int64_t total = (int64_t)N * HW * C;
+    if (x_dtype == BG_BF16 && y_dtype == BG_BF16 && C % 8 == 0 && (int64_t)N * HW < (int64_t(1) << 31) &&
+        ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0) {
+        hipLaunchKernelGGL(bn_apply_act_fwd_bf16x8_kernel, dim3(bn_x8_grid((int64_t)N * HW, C / 8)), dim3(EW_BLOCK), 0,
+                           as_stream(stream), (const __bf16*)x, mean, rstd, gamma, beta, per_sample, alpha, (__bf16*)y,
+                           N * HW, HW, C / 8);
+        BG_LAUNCH_CHECK();
+        return BG_OK;
+    }
     if (C % 4 == 0)
         BG_DISPATCH_XY(x_dtype, y_dtype,
                        hipLaunchKernelGGL((bn_apply_act_fwd_t_kernel<4, TX, TY>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK),
@@ -2223,7 +2372,8 @@ int bg_bn_apply_act_bwd_reduce_t(const void* x, int x_dtype, const void* dy, int
     }
     BG_DISPATCH_XY(x_dtype, y_dtype,
                    BnBwdReduceFnT<TX, TY> fn{(const TX*)x, (const TY*)dy, mean, rstd, gamma, beta, alpha, per_sample, HW, C};
-                   launch_colreduce<3>(fn, part, (int64_t)N * C, HW, N, C, as_stream(stream)));
+                   launch_colreduce<3, sizeof(TX) == 2 && sizeof(TY) == 2>(fn, part, (int64_t)N * C, HW, N, C,
+                                                                           as_stream(stream)));
     BG_LAUNCH_CHECK();
     return BG_OK;
 }
@@ -2234,6 +2384,14 @@ int bg_bn_apply_act_bwd_dx_t(const void* x, int x_dtype, const void* dy, int y_d
     BG_REQUIRE(x && dy && mean && rstd && gamma && beta && cm && dx && N > 0 && HW > 0 && C > 0 && BG_DT_OK(x_dtype) &&
                    BG_DT_OK(y_dtype), "bg_bn_apply_act_bwd_dx_t: bad argument");
     const int64_t total = (int64_t)N * HW * C;
+    if (x_dtype == BG_BF16 && y_dtype == BG_BF16 && C % 8 == 0 && (int64_t)N * HW < (int64_t(1) << 31) &&
+        ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0) {
+        hipLaunchKernelGGL(bn_apply_act_bwd_dx_bf16x8_kernel, dim3(bn_x8_grid((int64_t)N * HW, C / 8)), dim3(EW_BLOCK), 0,
+                           as_stream(stream), (const __bf16*)x, (const __bf16*)dy, mean, rstd, gamma, beta, per_sample,
+                           alpha, cm, (__bf16*)dx, N * HW, HW, C / 8);
+        BG_LAUNCH_CHECK();
+        return BG_OK;
+    }
     if (C % 4 == 0)
         BG_DISPATCH_XY(x_dtype, y_dtype,
                        hipLaunchKernelGGL((bn_apply_act_bwd_dx_t_kernel<4, TX, TY>), dim3(ew_grid(total / 4)),
@@ -2282,7 +2440,8 @@ int bg_prelu_bwd_t(const void* x, int x_dtype, const void* dy, int y_dtype, cons
     }
     if (dalpha) {
         BG_DISPATCH_XY(x_dtype, y_dtype, PreluDalphaFnT<TX, TY> fn{(const TX*)x, (const TY*)dy, C};
-                       launch_colreduce<1>(fn, dalpha, 0, rows, 1, C, as_stream(stream)));
+                       launch_colreduce<1, sizeof(TX) == 2 && sizeof(TY) == 2>(fn, dalpha, 0, rows, 1, C,
+                                                                               as_stream(stream)));
         BG_LAUNCH_CHECK();
     }
     return BG_OK;
@@ -2294,7 +2453,8 @@ int bg_bias_grad_t(const void* dy, int dtype, float* db, int64_t rows, int C, vo
         set_error("bg_bias_grad_t: memset failed");
         return BG_ERR_LAUNCH;
     }
-    BG_DISPATCH_T(dtype, BiasGradFnT<T> fn{(const T*)dy, C}; launch_colreduce<1>(fn, db, 0, rows, 1, C, as_stream(stream)));
+    BG_DISPATCH_T(dtype, BiasGradFnT<T> fn{(const T*)dy, C};
+                  launch_colreduce<1, sizeof(T) == 2>(fn, db, 0, rows, 1, C, as_stream(stream)));
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

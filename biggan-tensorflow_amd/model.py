@@ -298,7 +298,7 @@ class BigGAN(GANBase):
                     x = fully_connected(layer_z, units=f_width, scope='dense1', opt=opt)
                     x = opt["act"](x)
                     x = fully_connected(x, units=4 * 4 * ch, scope='dense2', opt=opt)
-            x = x.reshape(-1, 4, 4, ch)                                                # BigGAN.py:446
+            x = ops._resident_out(x.reshape(-1, 4, 4, ch))                             # BigGAN.py:446 (bf16 trunk from here)
 
             b_i = 0
             for block_count in counts:                                                 # BigGAN.py:449-489

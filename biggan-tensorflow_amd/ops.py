@@ -142,6 +142,8 @@ def _to(x, dtype):
 def _resident_out(y):
     """bf16-resident mode: a large activation produced by the fp32-tensor kernels (the image layers) joins the bf16
     part of the network."""
+    if _is_meta(y):
+        return y
     if Fn.Precision.resident and y.dtype == torch.float32 and y.dim() == 4 and y.shape[-1] % 8 == 0:
         return Fn.CastFn.apply(y, torch.bfloat16)
     return y
