@@ -43,6 +43,23 @@ def set_precision(mode):
         raise ValueError("precision %r: expected fp32, bf16-staged or bf16" % (mode,))
 
 
+class precision_scope:
+    """Run a region in another precision mode (the gradient penalty of a bf16-resident model: its inputs-only
+    backward and its forward-mode pass are fp32-tensor kernels, so they run as 'bf16-staged' - fp32 tensors, bf16 MFMA
+    operands, the same weights).  Functions record what they need in ctx at forward time, so the backward of the
+    region may run after the scope has ended."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = Precision.name
+        set_precision(self.mode)
+
+    def __exit__(self, *exc):
+        set_precision(self.prev)
+
+
 def cast(x, dtype):
     """Element-type conversion (RNE) by a HIP kernel; returns x itself when nothing changes."""
     if x.dtype == dtype:

@@ -619,6 +619,14 @@ class BigGAN(GANBase):
             Fn.check(L.bg_gp_interpolate(Fn.f32(real), Fn.f32(fake.detach().contiguous()), Fn.f32(draws["alpha"]), None,
                                          0.0, Fn.f32(xhat), B, per, Fn.stream()))
         aug = draws.get("aug")
+        if Fn.Precision.resident:          # bf16-resident model: the penalty's passes run on fp32 tensors (bf16 MFMA)
+            with Fn.precision_scope("bf16-staged"):
+                return self._gradient_penalty_passes(xhat, draws, aug, B, per)
+        return self._gradient_penalty_passes(xhat, draws, aug, B, per)
+
+    def _gradient_penalty_passes(self, xhat, draws, aug, B, per):
+        from .ops import Dual
+        L = Fn.lib()
         # (1) g = d sum(D(aug(x^))) / d x^
         xg = xhat.detach().requires_grad_(True)
         logit = self.discriminator(DiffAugment(xg, policy=self.da_policy, draws=aug), reuse=True)["real"]

@@ -302,6 +302,30 @@ def test_bf16_step_close_to_float64_oracle(mode, img, ch, B):
         Fn.set_precision("fp32")               # (a failing case must not leave the bf16 mode on for later tests)
 
 
+def test_bf16_gradient_penalty_step():
+    """--gan_type ra-dragan (the reference's default) with --precision bf16: the penalty's inputs-only backward and its
+    forward-mode pass run as fp32-tensor kernels with bf16 MFMA operands inside the bf16-resident step
+    (functional.precision_scope); d_loss and the penalty's value within 2e-2 of the float64 oracle, D gradients within
+    the bf16 gates of _check_grads."""
+    from oracle import ref_model as RM
+    from tests.common import oracle_trainer, hip_model_like, dev_draws
+    from biggan_tensorflow_amd import functional as Fn
+    try:
+        tr = oracle_trainer(64, 16, 64, 4, gan_type="ra-dragan")
+        gan = hip_model_like(tr, gan_type="ra-dragan", precision="bf16")
+        batch = RM.synthetic_batch(tr.cfg, 19, 4)
+        gpd = {"alpha": cu(batch["gp"]["alpha"]), "eps": cu(batch["gp"]["eps"]), "aug": dev_draws(batch["gp"]["aug"])}
+        ro = tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], apply=False, gp=batch["gp"])
+        ho = gan.d_step(cu(batch["real"]), cu(batch["z_d"]), dev_draws(batch["aug_real"]), dev_draws(batch["aug_fake_d"]),
+                        apply=False, gp_draws=gpd)
+        assert Fn.Precision.name == "bf16"
+        assert abs(ho["gp"].item() - ro["gp"].item()) <= 2e-2 * abs(ro["gp"].item()), (ho["gp"].item(), ro["gp"].item())
+        assert abs(ho["d_loss"].item() - ro["d_loss"].item()) <= 2e-2 * abs(ro["d_loss"].item())
+        _check_grads(gan, ro["grads"])
+    finally:
+        Fn.set_precision("fp32")
+
+
 def _bf16_step(mode, img, ch, B):
     from oracle import ref_model as RM
     from tests.common import oracle_trainer, hip_model_like, dev_draws

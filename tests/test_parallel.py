@@ -49,6 +49,16 @@ def _worker(rank, world, port, q):
     owner = g.reg_owner
     ok4 = (g.world == world and g.rank == rank and owner is not None and
            set(owner) == set(g.store.reg_shapes) and len(owner) == 42 and set(owner.values()) == set(range(world)))
+    # bench.py under this very process group: N > 1 runs BASELINE config 3 at its FIXED global batch
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    name, per_rank, mode = bench.resolve_workload("", dist.get_world_size())
+    total = torch.tensor([float(per_rank)])
+    dist.all_reduce(total)
+    ok4 = ok4 and name == "c3" and mode == "strong" and int(total.item()) == bench.GLOBAL_BATCH["c3"] == 256
     q.put((rank, ok1, ok2, ok3, lo, hi, ok4, sorted(owner.items())))
     dist.destroy_process_group()
 

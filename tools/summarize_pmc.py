@@ -30,6 +30,10 @@ def family(name):
 GEMM_FAMILY = r"\b((nn|tn)(16x?)?_kernel|attn(16)?_|rgb_|thin_|slab_reduce|reflect_fold)"
 
 
+# the plain GEMMs of the ortho-cosine regulariser (Gram matrices and their gradients: batch-independent, fp32 weights)
+REGULARISER = r"tn_kernel_bf16_tr<2>|nn_kernel_bf16<2, 2, false, 2, false, true>"
+
+
 def main():
     argv = sys.argv[1:]
     iterations = 0
@@ -86,7 +90,12 @@ def main():
                 rd += e["launches"] * e["hbm_read_bytes_per_launch"]
                 wr += e["launches"] * e.get("hbm_write_bytes_per_launch", 0.0)
                 us += e["launches"] * e["mean_us_under_pmc"]
+        reg = sum(res[f]["launches"] * (res[f]["hbm_read_bytes_per_launch"] + res[f].get("hbm_write_bytes_per_launch", 0.0))
+                  for f in fams if re.search(REGULARISER, f)) / iterations
         res["_summary"] = OrderedDict(iterations=iterations, gemm_family_regex=GEMM_FAMILY, gemm_families=fams,
+                                      regulariser_regex=REGULARISER,
+                                      regulariser_gemm_hbm_bytes_per_iteration=reg,
+                                      conv_attention_gemm_hbm_bytes_per_iteration=(rd + wr) / iterations - reg,
                                       gemm_family_hbm_read_bytes_per_iteration=rd / iterations,
                                       gemm_family_hbm_write_bytes_per_iteration=wr / iterations,
                                       gemm_family_hbm_bytes_per_iteration=(rd + wr) / iterations,
