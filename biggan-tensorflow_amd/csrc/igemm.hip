@@ -917,6 +917,7 @@ struct Tag {
         snprintf(s, sizeof(s), "%s N%d H%d Cin%d Cout%d Ho%d k%d s%d", op, d->N, d->H, d->Cin, d->Cout, d->Ho, d->k,
                  d->stride);
     }
+    Tag(const char* op, int m, int n, int k) { snprintf(s, sizeof(s), "%s M%d N%d K%d", op, m, n, k); }
     Tag(const char* op, const BgGemmDesc* d) {
         snprintf(s, sizeof(s), "%s M%d N%d K%d tA%d tB%d b%d", op, d->M, d->N, d->K, d->transA, d->transB, d->batch);
     }
@@ -1342,6 +1343,33 @@ int bg_gemm(const BgGemmDesc* d, const float* A, const float* B, const float* bi
                      (d->N % 4 == 0) && (d->ldb % 4 == 0) && (d->strideB % 4 == 0) && aligned16(B);
     ProfScope prof(as_stream(stream), flops, tag.s);
     return launch_tn(p, GATHER_PLAIN, vec, C, ws, ws_bytes, as_stream(stream), d->compute == BG_COMPUTE_BF16);
+}
+
+// Gram matrix of a bf16 row-major matrix: out[c1][c2] = sum_r a[r][c1] a[r][c2] (fp32), the ortho-cosine regulariser's
+// W^T W (utils.py:198) taken from the packed bf16 copy of w / sigma that the spectral-norm pass already wrote: the
+// pixel-reduction kernel in PLAIN mode with both operands the same matrix.
+static void gram16_params(const void* a, int rows, int cols, int ld, TN16Params& p) {
+    memset(&p, 0, sizeof(p));
+    p.A = a; p.Bv = a;
+    p.g.ld = ld; p.b_ld = ld;
+    p.Ca = cols; p.Cb = cols; p.Mf = cols; p.M = rows; p.out_ld = cols;
+}
+
+size_t bg_gram16_workspace_bytes(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    TN16Params p;
+    gram16_params(nullptr, rows, cols, cols, p);
+    return tn16_workspace_bytes(p);
+}
+
+int bg_gram16(const void* a, int rows, int cols, int ld, float* out, void* ws, size_t ws_bytes, void* stream) {
+    BG_REQUIRE(a && out && rows > 0 && cols > 0 && ld >= cols, "bg_gram16: bad argument");
+    BG_REQUIRE(cols % 8 == 0 && ld % 8 == 0, "bg_gram16: cols and ld must be multiples of 8");
+    TN16Params p;
+    gram16_params(a, rows, cols, ld, p);
+    Tag tag("gram16", cols, cols, rows);
+    ProfScope prof(as_stream(stream), 2.0 * rows * (double)cols * cols, tag.s);
+    return launch_tn16(p, GATHER_PLAIN, out, ws, ws_bytes, as_stream(stream));
 }
 
 }  // extern "C"

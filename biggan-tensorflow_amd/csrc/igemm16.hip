@@ -977,7 +977,8 @@ static bool plan_tn16x(const TN16Params& p, int* sk_out, int* rps_out) {
     static const int use_wide = getenv("BG_TN16_WIDE") ? atoi(getenv("BG_TN16_WIDE")) : 1;
     if (!use_wide || p.Mf <= 128 || p.M < 8 * TN16_BK) return false;
     // the kernel walks a power-of-two pixel grid by shifts (every BigGAN resolution is one); others take tn16_kernel
-    if (p.g.Wq <= 0 || p.g.Hq <= 0 || (p.g.Wq & (p.g.Wq - 1)) || (p.g.Hq & (p.g.Hq - 1))) return false;
+    if (p.g.k > 0 && (p.g.Wq <= 0 || p.g.Hq <= 0 || (p.g.Wq & (p.g.Wq - 1)) || (p.g.Hq & (p.g.Hq - 1)))) return false;
+    // (g.k == 0: plain rows, no pixel walk)
     const int tm = (p.Mf + 255) / 256, tn = (p.Cb + 127) / 128;
     static const int wantx = getenv("BG_TN16X_WANT") ? atoi(getenv("BG_TN16X_WANT")) : 512;
     int sk = wantx / (tm * tn);

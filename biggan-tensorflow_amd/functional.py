@@ -791,6 +791,8 @@ class SnBatch:
             wn.bg_name = (getattr(w, "bg_name", None) or "w%d" % i) + ":sn"
             wn.bg_grad = self.gwn_flat.narrow(0, offs[i], w.numel()).view(w.shape)
             wn.bg_touched = False
+            wn.bg_sigma = self.sigma.narrow(0, i, 1)
+            w.bg_sn_wn = wn                     # (the regulariser of w finds the packed copy of w / sigma through this)
             v = self.v_flat.narrow(0, r0, self.rows[i])
             r0 += (self.rows[i] + 3) // 4 * 4
             dw = getattr(w, "bg_grad", None)
@@ -1635,7 +1637,20 @@ class OrthoCosineRegFn(Function):
             ctx.w, ctx.dW = w, dW
             return loss
         A = torch.empty((c, c), dtype=torch.float32, device=dev)
-        gemm(W2, W2, A, c, c, rows, c, c, c, transA=True)               # A = W^T W
+        wn = getattr(w, "bg_sn_wn", None)
+        pk = getattr(wn, "bg_pack_p", None) if wn is not None else None
+        if (Precision.resident and pk is not None and kind == "ortho_cosine" and c % 8 == 0
+                and os.environ.get("BG_REG_GRAM", "") != "fp32"):              # (BG_REG_GRAM=fp32: A/B switch)
+            # bf16-resident mode: W^T W = sigma^2 (W/sigma)^T (W/sigma) from the packed bf16 copy of this run's spectral
+            # norm - half the bytes of the fp32 weight, which the staged form reads twice
+            L = lib()
+            nb = int(L.bg_gram16_workspace_bytes(rows, c))
+            ws = workspace(nb, dev)
+            check(L.bg_gram16(act(pk), rows, c, c, f32(A), f32(ws), nb, stream()))
+            check(L.bg_scale_dev(f32(A), f32(wn.bg_sigma), f32(A), A.numel(), stream()))
+            check(L.bg_scale_dev(f32(A), f32(wn.bg_sigma), f32(A), A.numel(), stream()))
+        else:
+            gemm(W2, W2, A, c, c, rows, c, c, c, transA=True)           # A = W^T W
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
         dA = torch.empty((c, c), dtype=torch.float32, device=dev)
         if kind == "ortho":                                              # utils.py:199-200: reg = A - I

@@ -147,6 +147,8 @@ SIGNATURES = {
                                     c_int64, _P]),
     "bg_adam_tf_ema_step_dev": (c_int, [_P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int64,
                                         _P]),
+    "bg_gram16_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "bg_gram16": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "bg_cast": (c_int, [_P, c_int, _P, c_int, c_int64, _P]),
     "bg_pad_channels": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, c_int64, c_int, _P]),
     "bg_weight_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),

@@ -229,6 +229,12 @@ int bg_spectral_norm_batch_fwd(const BgSnItem* items_dev, int n_items, void* ws,
 int bg_spectral_norm_batch_bwd(const BgSnItem* items_dev, int n_items, const uint64_t* enable_mask,
                                const uint64_t* accumulate_mask, void* ws, size_t ws_bytes, void* stream);
 
+/* Gram matrix out[c1][c2] = sum_r a[r][c1] * a[r][c2] (fp32, [cols][cols]) of a bf16 row-major matrix a[rows][ld]:
+ * the ortho-cosine regulariser's W^T W (utils.py:198) from the packed bf16 copy of w / sigma (BgSnItem.pack_p); the caller
+ * rescales by sigma^2.  cols % 8 == ld % 8 == 0; ws from bg_gram16_workspace_bytes (split-K slabs). */
+size_t bg_gram16_workspace_bytes(int rows, int cols);
+int bg_gram16(const void* a, int rows, int cols, int ld, float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Batch statistics + (conditional) batch-norm + PReLU (ops.py:532-537, 580-585, 611-643).
  *   x [N,HW,C].  stats: sums[0:C] = sum x, sums[C:2C] = sum x^2 over N*HW (fp64 accumulators, so the

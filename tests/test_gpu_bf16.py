@@ -302,6 +302,26 @@ def test_bf16_step_close_to_float64_oracle(mode, img, ch, B):
         Fn.set_precision("fp32")               # (a failing case must not leave the bf16 mode on for later tests)
 
 
+@pytest.mark.parametrize("rows,cols,ld", [(9 * 64, 64, 64), (16 * 96, 192, 192), (4608, 384, 384), (200, 24, 120)])
+def test_gram16_from_packed_weights(rows, cols, ld):
+    """bg_gram16: W^T W of a bf16 row-major matrix (the regulariser's Gram from the packed copy of w / sigma, also as a
+    column slice of a wider pack) against float64 on the same bf16 values: 1e-5 (fp32 accumulation of exact
+    products)."""
+    import biggan_tensorflow_amd  # noqa: F401
+    from biggan_tensorflow_amd import hip
+    from biggan_tensorflow_amd.hip import act, f32, stream, check
+    L = hip.lib()
+    rng = np.random.default_rng(rows + cols)
+    full = torch.tensor(rng.standard_normal((rows, ld)), dtype=torch.float32, device="cuda").to(torch.bfloat16)
+    a = full[:, :cols]
+    out = torch.empty((cols, cols), dtype=torch.float32, device="cuda")
+    nb = int(L.bg_gram16_workspace_bytes(rows, cols))
+    ws = hip.workspace(nb, "cuda")
+    check(L.bg_gram16(act(full), rows, cols, ld, f32(out), f32(ws), nb, stream()))
+    ref = a.double().cpu().numpy()
+    assert rel_err(t2n(out), ref.T @ ref) < 1e-5
+
+
 def test_bf16_gradient_penalty_step():
     """--gan_type ra-dragan (the reference's default) with --precision bf16: the penalty's inputs-only backward and its
     forward-mode pass run as fp32-tensor kernels with bf16 MFMA operands inside the bf16-resident step

@@ -31,7 +31,7 @@ GEMM_FAMILY = r"\b((nn|tn)(16x?)?_kernel|attn(16)?_|rgb_|thin_|slab_reduce|refle
 
 
 # the plain GEMMs of the ortho-cosine regulariser (Gram matrices and their gradients: batch-independent, fp32 weights)
-REGULARISER = r"tn_kernel_bf16_tr<2>|nn_kernel_bf16<2, 2, false, 2, false, true>"
+REGULARISER = r"tn_kernel_bf16_tr<2>|nn_kernel_bf16<2, 2, false, 2, false, true>|tn16x?_kernel<2>"
 
 
 def main():
