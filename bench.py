@@ -353,6 +353,8 @@ def main():
                   "value": t["value"], "unit": "images/sec", "ms_per_step": t["ms_per_step"], "global_batch": 256,
                   "dtype": "bf16", "storage_dtype": t["storage_dtype"], "steps": t["steps"],
                   "step_frac_of_peak": t["step_frac_of_peak"], "roofline": t.get("roofline"),
+                  "scaling_series": "this object is the N = 1 point of the `--gpus N` strong-scaling series (same workload, "
+                                    "same global batch 256); the headline value above is config 2 in fp32",
                   "companions": comp, "losses": t["losses"],
                   "per_gpu_share_32": {"value": per32["value"], "ms_per_step": per32["ms_per_step"],
                                        "note": "one rank's work of the 8-GPU run (32 images per step), without collectives"}}
@@ -377,6 +379,9 @@ def main():
                        "storage_dtype": res["storage_dtype"], "parallelism": "dp%d" % world},
             "losses": res["losses"],
         }
+        if world > 1 and scaling == "strong":
+            out["config"]["scaling_series"] = ("N = 1 point of this series: the 'target' object of the --gpus 1 line "
+                                               "(this workload at global batch %d on one GPU)" % (B * world))
         if "roofline" in res:
             out["roofline"] = res["roofline"]
         if cpu is not None:
