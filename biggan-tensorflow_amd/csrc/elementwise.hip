@@ -1434,7 +1434,21 @@ __device__ __forceinline__ void sn_rowdot_body(const float* __restrict__ w, cons
         }
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         if ((cols & 3) == 0) {
-            for (int c = lane * 4; c < cols; c += 256) {
+            int c = lane * 4;
+            for (; c + 256 < cols; c += 512) {           // eight 16-byte loads of W in flight per lane
+                const float4 b0 = ldg4(u + c), b1 = ldg4(u + c + 256);
+                float4 a0[4], a1[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a0[k] = ldg4(wr[k] + c);
+                    a1[k] = ldg4(wr[k] + c + 256);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    s[k] += (a0[k].x * b0.x + a0[k].y * b0.y + a0[k].z * b0.z + a0[k].w * b0.w) +
+                            (a1[k].x * b1.x + a1[k].y * b1.y + a1[k].z * b1.z + a1[k].w * b1.w);
+            }
+            for (; c < cols; c += 256) {
                 const float4 b = ldg4(u + c);
                 float4 a[4];
 #pragma unroll
@@ -1624,7 +1638,8 @@ __device__ __forceinline__ double* sn_scr(const BgSnItem& it, char* ws) {
 __device__ __forceinline__ int sn_units_of(const BgSnItem& it, int kind) {
     const int64_t n = (int64_t)it.rows * it.cols;
     if (kind == 1) return sn_colsum_units(it.rows, it.cols);
-    const int64_t per = kind == 2 ? SN_UNIT_ELEMS / 2 : kind == 3 ? SN_UNIT_ELEMS_REDUCE : SN_UNIT_ELEMS;
+    const int64_t per = kind == 2 ? SN_UNIT_ELEMS / 2 : kind == 3 ? SN_UNIT_ELEMS_REDUCE : kind == 4 ? 4 * SN_UNIT_ELEMS
+                                                                                                  : SN_UNIT_ELEMS;
     const int64_t u = (n + per - 1) / per;
     return u < 1 ? 1 : (int)u;
 }
@@ -1654,7 +1669,7 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_batch_rowdot_kernel(const BgSnIte
     __shared__ int start[257];
     // 64 KB units and NO atomic: sum v_^2 is taken from v_ itself by the item's finalize block (a same-address atomic
     // per wave capped this pass at 1.9 TB/s with 1 MB units, and at 1.2 TB/s with small ones)
-    const int total = sn_sched_build(start, items, n_items, 0, nullptr);
+    const int total = sn_sched_build(start, items, n_items, 4, nullptr);      // 256 KB units: ~10 rows per wave
     for (int unit = blockIdx.x; unit < total; unit += gridDim.x) {
         const int j = sn_sched_find(start, n_items, unit);
         const BgSnItem it = items[j];
