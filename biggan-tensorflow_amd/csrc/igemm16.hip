@@ -420,6 +420,288 @@ __global__ __launch_bounds__(256) void nn16_slab_reduce_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------
+// NN kernel, halo-tile form: stride-1 window gathers (3 x 3 convolutions forward, 3 x 3 transposed convolutions in
+// both directions, each stride phase of a 4 x 4 stride-2 transposed convolution = a 2 x 2 window on the input grid).
+//   nn16_kernel re-reads the source pixels once per tap: on the C <= 192 layers (the high-resolution end of every
+//   generator / discriminator, most of the FLOPs of the 256^2 / 512^2 models) it is bound by L2 -> LDS bandwidth on
+//   that 9-fold im2col re-read (measured r02: ~7 TB/s of TCC traffic at 0.24 - 0.30 MFMA busy).  Here a block owns a
+//   16 x 16 patch of output pixels of one image and a slice of BN output channels; per 64-channel chunk it loads the
+//   (16 + NT - 1)^2 source pixels ONCE into LDS (128-byte pixel rows, 16-byte chunks XOR-swizzled by (pixel & 6): found by
+//   brute force to be conflict-free for a 16-lane fragment starting at ANY pixel, i.e. for every tap shift), and the
+//   NT^2 taps read their operands from that tile at shifted pixel indices while only the weight tile of each
+//   (chunk, tap) streams in through a 3-stage ring.  L2 -> LDS bytes per MAC: 0.0098 against 0.031.
+//   8 waves = 4 (pixel rows) x 2 (channels), wave tile 64 pixels x 16 NF channels, v_mfma_f32_16x16x32_bf16.
+// ------------------------------------------------------------------------------------------
+constexpr int NH_T = 16;                                   // patch edge
+template <int NT> struct NHGeom {
+    static constexpr int HW = NH_T + NT - 1;               // halo edge
+    static constexpr int NPIX = HW * HW;
+    static constexpr int A_INSTR = (NPIX * 8 + 511) / 512; // LDS-DMA instructions per thread and chunk
+    static constexpr int A_BYTES = A_INSTR * 8192;
+};
+constexpr int nh_w_instr(int NF) { return (32 * NF * 8 + 511) / 512; }
+template <int NT, int NF> constexpr int nn16h_lds_bytes() {
+    const int ring = 2 * NHGeom<NT>::A_BYTES + 3 * nh_w_instr(NF) * 8192;
+    const int epi = 256 * (32 * NF + 4) * 4;
+    return ring > epi ? ring : epi;
+}
+
+template <int NT, int NF, int MODE>
+__global__ __launch_bounds__(512, 1) void nn16h_kernel(const NN16Params p) {
+    using G = NHGeom<NT>;
+    constexpr int WW = G::HW, NPIX = G::NPIX, A_INSTR = G::A_INSTR, A_BYTES = G::A_BYTES;
+    constexpr int BN = 32 * NF, W_INSTR = nh_w_instr(NF), W_BYTES = W_INSTR * 8192, NTAPS = NT * NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // A0 | A1 | W0 | W1 | W2
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const Gather& g = p.g;
+
+    // ---- which patch ----
+    const int nph = g.pstep * g.pstep;
+    const int tiles_x = (g.Wq + NH_T - 1) / NH_T, tiles_y = (g.Hq + NH_T - 1) / NH_T;
+    const int nt = (p.N + BN - 1) / BN;
+    int r = xcd_remap(blockIdx.x, gridDim.x);
+    const int phase = r % nph; r /= nph;
+    const int tile_n = r % nt; r /= nt;
+    const int tx = r % tiles_x; r /= tiles_x;
+    const int ty = r % tiles_y;
+    const int b = r / tiles_y;
+    const int y0 = ty * NH_T, x0 = tx * NH_T, n0 = tile_n * BN;
+    int ph = 0, pw = 0;
+    if (MODE == GATHER_TCONV && g.pstep > 1) {
+        ph = g.pstep - 1 - phase / g.pstep;
+        pw = g.pstep - 1 - phase % g.pstep;
+    }
+    // window geometry per axis: halo index hi in [0, NT) <-> weight tap, source = q + base + hi
+    //   CONV  (stride 1): source = q + kh - pad                    -> base = -pad,            tap(hi) = hi
+    //   TCONV (stride 1): source = q + pad - kh                    -> base = pad - (NT - 1),  tap(hi) = NT - 1 - hi
+    //   TCONV phase     : kh = kh0 + 2 i, source = q + d - i       -> base = d - (NT - 1),    tap(hi) = kh0 + 2 (NT - 1 - hi)
+    int base_h, base_w, kh0 = 0, kw0 = 0, kstep = 1;
+    if (MODE == GATHER_CONV) {
+        base_h = base_w = -g.pad;
+    } else if (g.pstep > 1) {
+        kstep = g.stride;
+        kh0 = (ph + g.pad) % g.stride;
+        kw0 = (pw + g.pad) % g.stride;
+        base_h = (ph + g.pad - kh0) / g.stride - (NT - 1);
+        base_w = (pw + g.pad - kw0) / g.stride - (NT - 1);
+    } else {
+        base_h = base_w = g.pad - (NT - 1);
+    }
+
+    const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.A);
+    const unsigned char* bbase = reinterpret_cast<const unsigned char*>(p.B);
+    const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero_page);
+    const uint32_t lds0 = static_cast<uint32_t>(
+        reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem));
+    const uint32_t ldsw = lds0 + 2 * A_BYTES;
+
+    // ---- per-lane sources of the halo tile (fixed for the whole block) ----
+    const unsigned char* asrc[A_INSTR];
+    int acb[A_INSTR];                                   // byte offset of this lane's 8 channels inside a 64-channel chunk
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int pp = (i * 8 + w) * 64 + lane;
+        const int q = pp >> 3, c = (pp & 7) ^ (q & 6);
+        const int hy = q / WW, hx = q - hy * WW;
+        int sy = y0 + hy + base_h, sx = x0 + hx + base_w;
+        bool ok = q < NPIX;
+        if (MODE == GATHER_CONV && g.reflect) {
+            sy = sy < 0 ? -sy : sy;
+            sy = sy >= g.Hs ? 2 * (g.Hs - 1) - sy : sy;
+            sx = sx < 0 ? -sx : sx;
+            sx = sx >= g.Ws ? 2 * (g.Ws - 1) - sx : sx;
+        }
+        ok = ok && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+        acb[i] = 16 * c;
+        asrc[i] = ok ? abase + 2 * ((int64_t)((b * g.Hs + sy) * g.Ws + sx) * g.ld) : zero;
+    }
+    const unsigned char* wsrc[W_INSTR];
+    int wcb[W_INSTR];
+    bool wok[W_INSTR];
+#pragma unroll
+    for (int i = 0; i < W_INSTR; ++i) {
+        const int pp = (i * 8 + w) * 64 + lane;
+        const int n = pp >> 3, c = (pp & 7) ^ ((n >> 1) & 7);
+        wok[i] = n < BN && n0 + n < p.N;
+        wcb[i] = 16 * c;
+        wsrc[i] = bbase + 2 * ((int64_t)(n0 + n) * p.C);
+    }
+    const uint32_t dma_a = __builtin_amdgcn_readfirstlane(lds0 + w * 1024);
+    const uint32_t dma_w = __builtin_amdgcn_readfirstlane(ldsw + w * 1024);
+
+    auto issue_a = [&](int chunk) {                     // the (NT + 15)^2 source pixels of 64 channels
+        const uint32_t dst = dma_a + (chunk & 1) * A_BYTES;
+        const int cb = chunk * 128;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const bool cv = (cb + acb[i]) < 2 * p.C;
+            glds16_asm(cv ? asrc[i] + (cb + acb[i]) : zero, dst + i * 8192);
+        }
+    };
+    auto issue_w = [&](int step) {                      // weight tile [BN][64 channels] of (chunk, tap)
+        const int chunk = step / NTAPS, tap = step - chunk * NTAPS;
+        const int hy = tap / NT, hx = tap - hy * NT;
+        const int kh = MODE == GATHER_CONV ? hy : kh0 + kstep * (NT - 1 - hy);
+        const int kw = MODE == GATHER_CONV ? hx : kw0 + kstep * (NT - 1 - hx);
+        const int64_t toff = 2 * ((int64_t)(kh * g.k + kw) * p.tap_stride);
+        const uint32_t dst = dma_w + (step % 3) * W_BYTES;
+        const int cb = chunk * 128;
+#pragma unroll
+        for (int i = 0; i < W_INSTR; ++i) {
+            const bool cv = wok[i] && (cb + wcb[i]) < 2 * p.C;
+            glds16_asm(cv ? wsrc[i] + toff + (cb + wcb[i]) : zero, dst + i * 8192);
+        }
+    };
+
+    // ---- operand addresses ----
+    const int px = lane & 15, kb = lane >> 4;
+    int qb[4];                                          // halo pixel of this lane's output pixel at tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qb[i] = (wm * 4 + i) * WW + px;
+    uint32_t boff[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int n = wn * 16 * NF + 16 * j + px;
+        boff[j] = 2 * A_BYTES + n * 128 + 16 * (kb ^ ((n >> 1) & 7));      // (byte offset into smem)
+    }
+
+    f32x4_t acc[4][NF];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    const int nchunks = (p.C + 63) >> 6;
+    const int T = nchunks * NTAPS;
+    issue_a(0);
+    issue_w(0);
+    if (T > 1) issue_w(1);
+
+    for (int step = 0; step < T; ++step) {
+        const int chunk = step / NTAPS, tap = step - chunk * NTAPS;
+        // wait for W(step) (and, at a chunk's first tap, its halo tile); what may stay in flight behind it:
+        //   W(step + 1), and at tap 1 the next chunk's halo tile issued one step ago in front of W(step + 1)
+        const bool more_w = step + 1 < T;
+        const bool a_behind = tap == 1 && chunk + 1 < nchunks;
+        if (more_w && a_behind) {
+            if (A_INSTR + W_INSTR == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (A_INSTR + W_INSTR == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        } else if (more_w) {
+            if (W_INSTR == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (tap == 0 && chunk + 1 < nchunks) issue_a(chunk + 1);     // (its buffer was last read one chunk ago)
+        if (step + 2 < T) issue_w(step + 2);
+
+        const int hy = tap / NT, hx = tap - hy * NT;
+        const uint32_t abuf = (chunk & 1) * A_BYTES;
+        const uint32_t wslot = (uint32_t)(step % 3) * W_BYTES;
+        const int tq = hy * WW + hx;
+        const int ksteps = (p.C - chunk * 64) >= 64 ? 2 : 1;           // 32-channel MFMA steps in this chunk
+        uint32_t aaddr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = qb[i] + tq;
+            aaddr[i] = abuf + q * 128 + 16 * (kb ^ (q & 6));
+        }
+        if (ksteps == 2) {
+            // all operand reads of the step up front: the second half lands behind the first half's MFMAs
+            bf16x8_t a[2][4], bw[2][NF];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[s2][i] = *reinterpret_cast<const bf16x8_t*>(smem + (aaddr[i] ^ (s2 ? 64u : 0u)));
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    bw[s2][j] = *reinterpret_cast<const bf16x8_t*>(smem + ((boff[j] + wslot) ^ (s2 ? 64u : 0u)));
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[s2][j], a[s2][i], acc[i][j], 0, 0, 0);
+        } else {                                        // the 32-channel tail of C = 96, 160, ...
+            bf16x8_t a[4], bw[NF];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(smem + aaddr[i]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) bw[j] = *reinterpret_cast<const bf16x8_t*>(smem + boff[j] + wslot);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: accumulators -> LDS [256][BN + 4] fp32 -> 16-byte row segments ----
+    constexpr int ELD = BN + 4;
+    float* est = reinterpret_cast<float*>(smem);
+    const float alpha = p.alpha ? *p.alpha : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int row = (wm * 4 + i) * 16 + px;
+            const int col = wn * 16 * NF + 16 * j + 4 * kb;
+            f32x4_t v = acc[i][j];
+            v[0] *= alpha; v[1] *= alpha; v[2] *= alpha; v[3] *= alpha;
+            *reinterpret_cast<f32x4_t*>(est + row * ELD + col) = v;
+        }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+    for (int idx = t; idx < 256 * CPR; idx += 512) {
+        const int row = idx / CPR, cc = idx - row * CPR;
+        const int gy = y0 + (row >> 4), gx = x0 + (row & 15), col = n0 + cc * 8;
+        if (gy >= g.Hq || gx >= g.Wq || col >= p.N) continue;
+        const int oy = gy * g.pstep + ph, ox = gx * g.pstep + pw;
+        if (oy >= g.Ho || ox >= g.Wo) continue;
+        const int64_t ooff = ((int64_t)(b * g.Ho + oy) * g.Wo + ox) * p.out_ld + col;
+        f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(est + row * ELD + cc * 8);
+        f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(est + row * ELD + cc * 8 + 4);
+        if (p.bias) {
+            v0 += *reinterpret_cast<const f32x4_t*>(p.bias + col);
+            v1 += *reinterpret_cast<const f32x4_t*>(p.bias + col + 4);
+        }
+        if (p.out_f32) {
+            float* o = reinterpret_cast<float*>(p.out) + ooff;
+            if (p.accumulate) {
+                v0 += *reinterpret_cast<const f32x4_t*>(o);
+                v1 += *reinterpret_cast<const f32x4_t*>(o + 4);
+            }
+            *reinterpret_cast<f32x4_t*>(o) = v0;
+            *reinterpret_cast<f32x4_t*>(o + 4) = v1;
+        } else {
+            __bf16* o = reinterpret_cast<__bf16*>(p.out) + ooff;
+            if (p.accumulate) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(o);
+                v0[0] += bf16_lo(rr.x); v0[1] += bf16_hi(rr.x); v0[2] += bf16_lo(rr.y); v0[3] += bf16_hi(rr.y);
+                v1[0] += bf16_lo(rr.z); v1[1] += bf16_hi(rr.z); v1[2] += bf16_lo(rr.w); v1[3] += bf16_hi(rr.w);
+            }
+            uint4 rr;
+            rr.x = pack_bf16x2(v0[0], v0[1]);
+            rr.y = pack_bf16x2(v0[2], v0[3]);
+            rr.z = pack_bf16x2(v1[0], v1[1]);
+            rr.w = pack_bf16x2(v1[2], v1[3]);
+            *reinterpret_cast<uint4*>(o) = rr;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // TN kernel (weight gradients): K = pixels, both operands pixel-major in LDS, transposed operand reads
 // ------------------------------------------------------------------------------------------
 constexpr int TN16_BK = 64;
@@ -909,6 +1191,70 @@ static int launch_nn16_mode(const NN16Params& p, int tn, dim3 grid, hipStream_t 
     }
 }
 
+// ---- halo-tile form: which launches take it ----
+static int nn16h_taps(const NN16Params& p, int mode, int zdim) {
+    // Opt-in (BG_NN16_HALO=1, read per call so that a test can switch it): measured r02 on config 3 at batch 256 it is
+    // 10 - 20 % SLOWER than nn16_kernel on every layer it covers (forward sum 10.65 -> 11.87 ms) although it moves a third
+    // of the L2 -> LDS bytes: one 8-wave block per CU (147 KB of LDS) leaves nothing to run while a block is in its
+    // prologue (per-lane halo addresses, first tiles) or epilogue, and K is short where the halo helps most (18 steps at
+    // C = 96).  A 4-wave / 2-blocks-per-CU form (one halo buffer, 2-stage weight ring) is the next thing to try.
+    const char* e = getenv("BG_NN16_HALO");
+    const int use = e ? atoi(e) : 0;
+    static const int cmax = getenv("BG_NN16_HALO_CMAX") ? atoi(getenv("BG_NN16_HALO_CMAX")) : 4096;
+    const Gather& g = p.g;
+    if (!use || p.C > cmax || p.C % 32 || p.N % 8 || g.Hq < NH_T || g.Wq < NH_T || g.Hq % NH_T || g.Wq % NH_T) return 0;
+    if (mode == GATHER_CONV) return (g.stride == 1 && g.k == 3 && g.pstep == 1 && zdim == 1) ? 3 : 0;
+    if (g.reflect) return 0;
+    if (g.stride == 1 && g.k == 3 && g.pstep == 1 && zdim == 1) return 3;
+    if (g.stride == 2 && g.k == 4 && g.pstep == 2 && zdim == 4) return 2;
+    return 0;
+}
+
+template <int NT, int NF, int MODE>
+static int launch_nn16h_inst(const NN16Params& p, int blocks, hipStream_t s) {
+    constexpr int lds = nn16h_lds_bytes<NT, NF>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nn16h_kernel<NT, NF, MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            set_error("nn16h: cannot raise the dynamic LDS limit to %d bytes", lds);
+            return BG_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((nn16h_kernel<NT, NF, MODE>), dim3(blocks), dim3(512), lds, s, p);
+    return BG_OK;
+}
+
+template <int NT, int MODE>
+static int launch_nn16h_nf(const NN16Params& p, int nf, int blocks, hipStream_t s) {
+    switch (nf) {
+        case 2: return launch_nn16h_inst<NT, 2, MODE>(p, blocks, s);
+        case 3: return launch_nn16h_inst<NT, 3, MODE>(p, blocks, s);
+        default: return launch_nn16h_inst<NT, 4, MODE>(p, blocks, s);
+    }
+}
+
+static int launch_nn16h(NN16Params& p, int mode, int ntaps, hipStream_t s) {
+    int nf = 4, best = 1 << 30;
+    for (int c = 4; c >= 2; --c) {                      // least padded output channels; ties: the wider tile
+        const int padded = (p.N + 32 * c - 1) / (32 * c) * (32 * c);
+        if (padded < best) { best = padded; nf = c; }
+    }
+    const Gather& g = p.g;
+    const int64_t blocks = (int64_t)g.Nb * (g.Hq / NH_T) * (g.Wq / NH_T) * ((p.N + 32 * nf - 1) / (32 * nf)) *
+                           (g.pstep * g.pstep);
+    BG_REQUIRE(blocks > 0 && blocks < (int64_t(1) << 31), "nn16h: grid out of range");
+    p.splitk = 1;
+    int rc;
+    if (mode == GATHER_CONV) rc = launch_nn16h_nf<3, GATHER_CONV>(p, nf, (int)blocks, s);
+    else if (ntaps == 3) rc = launch_nn16h_nf<3, GATHER_TCONV>(p, nf, (int)blocks, s);
+    else rc = launch_nn16h_nf<2, GATHER_TCONV>(p, nf, (int)blocks, s);
+    if (rc) return rc;
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
 int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, size_t ws_bytes, hipStream_t s) {
     BG_REQUIRE(p.C % 8 == 0 && p.N % 8 == 0 && p.g.ld % 8 == 0 && p.out_ld % 8 == 0,
                "bf16-resident conv: channel counts must be multiples of 8 (C=%d N=%d)", p.C, p.N);
@@ -919,6 +1265,7 @@ int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, 
                "bf16-resident conv: kernel size %d / stride %d / %d channels not supported", p.g.k, p.g.stride, p.C);
     BG_REQUIRE((int64_t)p.g.Nb * p.g.Hs * p.g.Ws < (int64_t(1) << 30) && (int64_t)p.g.Nb * p.g.Ho * p.g.Wo < (int64_t(1) << 31),
                "bf16-resident conv: more than 2^30 source / 2^31 output pixels");
+    if (const int ntaps = nn16h_taps(p, mode, zdim)) return launch_nn16h(p, mode, ntaps, s);
     NN16Plan pl = plan_nn16(p, mode, zdim, ws != nullptr);
     if (pl.splitk > 1 && ws_bytes < (size_t)pl.splitk * out_elems * sizeof(float)) pl.splitk = 1;
     p.splitk = pl.splitk;

@@ -6,6 +6,8 @@
 
 Stated tolerance: relative L2 error <= 1e-2 against the float64 reference on the un-rounded inputs (bf16 has an
 8-bit mantissa: unit round-off 2^-9 = 2e-3 per operand; measured errors are 2e-3..5e-3)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -300,6 +302,38 @@ def test_bf16_step_close_to_float64_oracle(mode, img, ch, B):
         _bf16_step(mode, img, ch, B)
     finally:
         Fn.set_precision("fp32")               # (a failing case must not leave the bf16 mode on for later tests)
+
+
+@pytest.mark.parametrize("kind,N,H,Cin,Cout,k,s", [("conv", 2, 16, 64, 128, 3, 1), ("conv", 2, 32, 96, 96, 3, 1),
+                                                   ("conv", 1, 32, 160, 200, 3, 1), ("deconv", 2, 16, 64, 64, 3, 1),
+                                                   ("deconv", 2, 16, 128, 64, 4, 2), ("deconv", 1, 32, 96, 192, 4, 2)])
+def test_halo_tile_kernel_matches_the_tap_kernel(kind, N, H, Cin, Cout, k, s):
+    """nn16h_kernel (opt-in, BG_NN16_HALO=1): the same launches through the halo-tile form and through nn16_kernel give
+    the same bf16 results up to the order of the fp32 accumulation (<= 1 bf16 ulp: 8e-3 relative on single elements,
+    1e-3 relative L2), forward and input gradient, incl. reflect padding, the 32-channel tail of C = 96 / 160, ragged
+    output-channel tiles and the four stride phases of a 4 x 4 transposed convolution."""
+    from biggan_tensorflow_amd import functional as Fn, hip
+    Fn.set_precision("bf16")
+    try:
+        rng = np.random.default_rng(N + H + Cin + Cout + k)
+        x = cu(rng.standard_normal((N, H, H, Cin)), dtype=torch.bfloat16)
+        outs = []
+        for halo in ("0", "1"):
+            os.environ["BG_NN16_HALO"] = halo
+            xc = x.clone().requires_grad_(True)
+            if kind == "conv":
+                w = cu(rng.standard_normal((k, k, Cin, Cout)) * 0.1 if not outs else outs[0][2], True)
+                y = Fn.Conv2dFn.apply(xc, w, None, s, 1, H, H, hip.PAD_REFLECT)
+            else:
+                w = cu(rng.standard_normal((k, k, Cout, Cin)) * 0.1 if not outs else outs[0][2], True)
+                y = Fn.Deconv2dFn.apply(xc, w, None, s, 1, None)
+            g = cu(np.random.default_rng(7).standard_normal(tuple(y.shape)), dtype=torch.bfloat16)
+            y.backward(g)
+            outs.append((f64(y), f64(xc.grad), t2n(w.detach())))
+        assert rel_err(outs[1][0], outs[0][0]) < 1e-3 and rel_err(outs[1][1], outs[0][1]) < 1e-3
+    finally:
+        os.environ.pop("BG_NN16_HALO", None)
+        Fn.set_precision("fp32")
 
 
 @pytest.mark.parametrize("rows,cols,ld", [(9 * 64, 64, 64), (16 * 96, 192, 192), (4608, 384, 384), (200, 24, 120)])
