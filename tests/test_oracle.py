@@ -475,3 +475,110 @@ def test_gradient_penalty_finite_differences(gan_type):
             fd = (vals[0] - vals[1]) / (2 * eps)
             an = gd[name].reshape(-1)[idx].item()
             assert abs(fd - an) <= 2e-5 * max(1e-3, abs(an), abs(fd)) + 1e-8, (name, idx, fd, an)
+
+
+# ----------------------------------------------------------------------------------
+# More known answers PUBLISHED by TensorFlow's API documentation, restated ("the remaining lever is widening
+# the TF-published KAT set").  Each checks the oracle function a reference call site maps to against the formula or
+# worked example the TF docs give for that op, written independently of the oracle's own (numerically stable) form.
+# ----------------------------------------------------------------------------------
+def test_tf_sigmoid_cross_entropy_documented_definition():
+    """tf.nn.sigmoid_cross_entropy_with_logits docs: loss = z * -log(sigmoid(x)) + (1 - z) * -log(1 - sigmoid(x)), and the
+    stable form max(x, 0) - x * z + log(1 + exp(-abs(x))) 'to ensure stability and avoid overflow' (utils.py:366-369 via
+    cls_loss_fn; ops.py:763-777 for the gan / dragan losses with labels of ones / zeros)."""
+    rng = np.random.default_rng(0)
+    x = torch.tensor(rng.standard_normal((5, 7)) * 3.0, dtype=F64)
+    z = torch.tensor(rng.integers(0, 2, (5, 7)).astype(np.float64))
+    w = torch.tensor(rng.uniform(0.5, 2.0, (7,)), dtype=F64)
+    sig = 1.0 / (1.0 + np.exp(-x.numpy()))
+    definition = z.numpy() * -np.log(sig) + (1 - z.numpy()) * -np.log(1 - sig)
+    assert abs(R.cls_loss_logistic(z, x, w).item() - (definition * w.numpy()).mean()) < 1e-12
+    assert np.allclose(R._sce(True, x).numpy(), -np.log(sig), atol=1e-12)
+    assert np.allclose(R._sce(False, x).numpy(), -np.log(1 - sig), atol=1e-12)
+    big = torch.tensor([[80.0, -80.0]], dtype=F64)                 # the documented reason for the stable form
+    assert torch.isfinite(R._sce(True, big)).all() and torch.isfinite(R._sce(False, big)).all()
+
+
+def test_tf_l2_normalize_documented_formula():
+    """tf.nn.l2_normalize docs: output = x / sqrt(max(sum(x**2), epsilon)), epsilon = 1e-12 (ops.py:733,736)."""
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((1, 9))
+    assert np.allclose(R.l2_normalize(torch.tensor(x)).numpy(), x / np.sqrt(max((x ** 2).sum(), 1e-12)), atol=1e-15)
+    tiny = np.full((1, 4), 1e-9)                                   # sum of squares 4e-18 < epsilon: divided by 1e-6
+    assert np.allclose(R.l2_normalize(torch.tensor(tiny)).numpy(), tiny / 1e-6, rtol=1e-12)
+
+
+def test_tf_moments_and_batch_normalization_documented_formulas():
+    """tf.nn.moments docs: 'the mean and variance of x' over the axes (population variance); tf.nn.batch_normalization
+    docs: (x - mean) / sqrt(variance + epsilon) * scale + offset (ops.py:630-638), and tf.layers.batch_normalization's
+    moving averages moving = moving * momentum + batch * (1 - momentum) (ops.py:581-585)."""
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((4, 3, 3, 5)) * 2.0 + 1.0
+    vs = R.VarStore()
+    opt = {"bn_momentum": 0.9}
+    y = R.batch_norm(vs, "bn", torch.tensor(x), opt, is_training=True).detach().numpy()
+    mean, var = x.mean(axis=(0, 1, 2)), x.var(axis=(0, 1, 2))        # numpy var = population variance
+    assert np.allclose(y, (x - mean) / np.sqrt(var + 1e-5), atol=1e-12)   # gamma = 1, beta = 0 at initialisation
+    vs.commit()
+    n = 4 * 3 * 3
+    assert np.allclose(vs.vars["bn/moving_mean"].numpy(), 0.0 * 0.9 + mean * 0.1, atol=1e-14)
+    assert np.allclose(vs.vars["bn/moving_variance"].numpy(), 1.0 * 0.9 + var * n / (n - 1) * 0.1, atol=1e-14)
+    y_inf = R.batch_norm(vs, "bn", torch.tensor(x), opt, is_training=False).detach().numpy()
+    mm, mv = vs.vars["bn/moving_mean"].numpy(), vs.vars["bn/moving_variance"].numpy()
+    assert np.allclose(y_inf, (x - mm) / np.sqrt(mv + 1e-5), atol=1e-12)
+
+
+def test_tf_same_padding_documented_arithmetic():
+    """TF 'SAME' padding as documented for tf.nn.conv2d: out = ceil(in / stride), pad_along = max((out - 1) * stride +
+    filter - in, 0), pad_top = pad_along // 2, pad_bottom = pad_along - pad_top - the odd pixel goes to the bottom /
+    right (--conv_padding zero, ops.py:77-80); checked on the documented worked sizes and against a direct-loop VALID
+    convolution of the explicitly padded input."""
+    assert kat.same_padding(13, 6, 5) == (3, 1, 2)      # TF docs' own example: in 13, filter 6, stride 5: 1 left, 2 right
+    assert kat.same_padding(8, 3, 2) == (4, 0, 1)
+    assert kat.same_padding(7, 3, 2) == (4, 1, 1)
+    rng = np.random.default_rng(3)
+    for H, k, s in ((8, 3, 2), (7, 3, 2), (6, 3, 1), (8, 4, 2)):
+        x = rng.standard_normal((2, H, H, 3))
+        vs = R.VarStore(seed=H)
+        y = R.conv(vs, "c", torch.tensor(x), 4, {"padding_type": "zero", "sn": False}, kernel=k, stride=s, pad=1,
+                   use_bias=False).detach().numpy()
+        out, lo, hi = kat.same_padding(H, k, s)
+        xp = np.pad(x, ((0, 0), (lo, hi), (lo, hi), (0, 0)))
+        ref = kat.conv2d_valid(xp, vs.vars["c/kernel"].detach().numpy(), s)
+        assert y.shape == (2, out, out, 4) and np.allclose(y, ref, atol=1e-12)
+
+
+def test_tf_pooling_and_resize_documented_semantics():
+    """tf.layers.max_pooling2d / average_pooling2d(pool 2, strides 2, VALID) take each non-overlapping 2 x 2 window
+    (ops.py:508-514); tf.image.resize_nearest_neighbor with align_corners = False maps output pixel i to input pixel
+    floor(i * in / out) (ops.py:516-519): for a factor of 2 every input pixel is repeated 2 x 2."""
+    x = np.arange(2 * 4 * 4 * 1, dtype=np.float64).reshape(2, 4, 4, 1)
+    mp = R.max_pooling(torch.tensor(x)).numpy()
+    ap = R.avg_pooling(torch.tensor(x)).numpy()
+    up = R.up_sample(torch.tensor(x)).numpy()
+    for b in range(2):
+        for i in range(2):
+            for j in range(2):
+                win = x[b, 2 * i:2 * i + 2, 2 * j:2 * j + 2, 0]
+                assert mp[b, i, j, 0] == win.max() and ap[b, i, j, 0] == win.mean()
+        for i in range(8):
+            for j in range(8):
+                assert up[b, i, j, 0] == x[b, (i * 4) // 8, (j * 4) // 8, 0]
+
+
+def test_tf_adam_documented_update_three_steps():
+    """tf.train.AdamOptimizer docs: lr_t = learning_rate * sqrt(1 - beta2^t) / (1 - beta1^t); m_t = beta1 * m + (1 - beta1) * g;
+    v_t = beta2 * v + (1 - beta2) * g * g; variable -= lr_t * m_t / (sqrt(v_t) + epsilon) - note epsilon OUTSIDE the bias
+    correction ('epsilon hat' of the paper), three consecutive steps on a scalar (BigGAN.py:923-927)."""
+    lr, b1, b2, eps = 2e-4, 0.0, 0.9, 1e-8
+    opt = M.AdamTF(lr, b1, b2, eps)
+    p = {"w": torch.tensor([0.5, -1.0], dtype=F64)}
+    grads = [np.array([0.3, -0.2]), np.array([-0.1, 0.4]), np.array([0.05, 0.05])]
+    w, m, v = np.array([0.5, -1.0]), np.zeros(2), np.zeros(2)
+    for t, g in enumerate(grads, 1):
+        opt.step(p, {"w": torch.tensor(g, dtype=F64)})
+        lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        w = w - lr_t * m / (np.sqrt(v) + eps)
+        assert np.allclose(p["w"].detach().numpy(), w, rtol=0, atol=1e-15)
