@@ -181,6 +181,91 @@ __global__ void bn_finalize_kernel(const double* sums, double count, float eps, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Forward-mode tangent of training-mode batch norm and its backward (the gradient penalty, BigGAN.py:717-742, through a
+// discriminator with --bn_in_d, ops.py:546-561).  With xh = (x - mu) r, r = rstd:
+//   tangent   yd = g r (xd - m1 - xh m2),            m1 = mean(xd), m2 = mean(xd xh)
+//   backward  (s = dL/dyd):  d_xd = g r (s - mean(s) - xh mean(s xh))          (the operator is symmetric)
+//             d_g  = r (sum(s xd) - m1 sum(s) - m2 sum(s xh))
+//             d_x  = xh (3 m2 Swx - Swu) / n - m2 w - (Swx / n)(xd - m1) + m2 Sw / n,   w = g r^2 s, S.. = sums of w (.)
+//   (derived in DESIGN section 7; checked against finite differences on the CPU: tests/test_oracle.py).
+// Everything elementwise is a per-channel linear combination of (s | xd), x and xd, so the pass is: one 3-quantity column
+// reduction (chan_dots), one single-block coefficient kernel, one lincomb kernel - forward and backward alike.
+// ------------------------------------------------------------------------------------------
+struct ChanDotsFn {            // sum p, sum p q, sum p r  (r may be null: third sum 0)
+    const float* p;
+    const float* q;
+    const float* r;
+    int C;
+    template <int VEC>
+    __device__ __forceinline__ void operator()(int, int64_t row, int c, float (&acc)[3][VEC]) const {
+        float pv[VEC], qv[VEC], rv[VEC];
+        loadv<VEC>(p + row * C + c, pv);
+        loadv<VEC>(q + row * C + c, qv);
+        if (r) loadv<VEC>(r + row * C + c, rv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            acc[0][j] += pv[j];
+            acc[1][j] += pv[j] * qv[j];
+            if (r) acc[2][j] += pv[j] * rv[j];
+        }
+    }
+};
+
+// forward coefficients: yd = cf[0] xd + cf[1] x + cf[2];  m12 = (m1 | m2) kept for the backward
+__global__ void bn_tangent_fwd_coefs_kernel(const double* __restrict__ sums, double count, const float* __restrict__ mean,
+                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                            float* __restrict__ cf, float* __restrict__ m12, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = mean[c], r = rstd[c], g = gamma[c];
+    const double m1 = sums[c] / count;
+    const double m2 = r * (sums[C + c] - mu * sums[c]) / count;
+    cf[c] = (float)(g * r);
+    cf[C + c] = (float)(-g * r * r * m2);
+    cf[2 * C + c] = (float)(-g * r * m1 + g * r * r * m2 * mu);
+    m12[c] = (float)m1;
+    m12[C + c] = (float)m2;
+}
+
+// backward coefficients from S = (sum s | sum s x | sum s xd):
+//   d_xd = cd[0] s + cd[1] x + cd[2];   d_x = cx[0] s + cx[1] x + cx[2] xd + cx[3];   dgamma
+__global__ void bn_tangent_bwd_coefs_kernel(const double* __restrict__ S, double count, const float* __restrict__ mean,
+                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                            const float* __restrict__ m12, float* __restrict__ cd, float* __restrict__ cx,
+                                            float* __restrict__ dgamma, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = mean[c], r = rstd[c], g = gamma[c], n = count;
+    const double m1 = m12[c], m2 = m12[C + c];
+    const double S1 = S[c], S2 = S[C + c], S3 = S[2 * C + c];
+    const double q = r * (S2 - mu * S1) / n;                 // mean(s xh)
+    cd[c] = (float)(g * r);
+    cd[C + c] = (float)(-g * r * r * q);
+    cd[2 * C + c] = (float)(-g * r * S1 / n + g * r * r * q * mu);
+    dgamma[c] = (float)(r * (S3 - m1 * S1 - m2 * n * q));
+    const double Sw = g * r * r * S1, Swx = g * r * r * n * q, Swu = g * r * r * (S3 - m1 * S1);
+    const double K = (3.0 * m2 * Swx - Swu) / n;
+    cx[c] = (float)(-m2 * g * r * r);
+    cx[C + c] = (float)(r * K);
+    cx[2 * C + c] = (float)(-Swx / n);
+    cx[3 * C + c] = (float)(-r * mu * K + (Swx / n) * m1 + m2 * Sw / n);
+}
+
+// out = cp[c] p + cq[c] q (+ cr[c] r) + c0[c]
+__global__ __launch_bounds__(EW_BLOCK) void chan_lincomb3_kernel(const float* __restrict__ p, const float* __restrict__ cp,
+                                                                  const float* __restrict__ q, const float* __restrict__ cq,
+                                                                  const float* __restrict__ r, const float* __restrict__ cr,
+                                                                  const float* __restrict__ c0, float* __restrict__ out,
+                                                                  int64_t total, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const int c = (int)(i % C);
+        float v = cp[c] * p[i] + cq[c] * q[i] + c0[c];
+        if (r) v += cr[c] * r[i];
+        out[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // batch renormalisation: clipped corrections r, d against running statistics (ops.py:600-609, 645-715)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void renorm_coeffs_kernel(const double* __restrict__ sums, double count,
@@ -1849,6 +1934,47 @@ int bg_bn_finalize(const double* sums, double count, float eps, float momentum, 
     BG_REQUIRE(sums && mean && rstd && C > 0 && count > 0, "bg_bn_finalize: bad argument");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count, eps,
                        momentum, unbiased_moving_var, mean, rstd, moving_mean, moving_var, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_chan_dots3(const float* p, const float* q, const float* r, double* sums, int64_t rows, int C, void* stream) {
+    BG_REQUIRE(p && q && sums && rows > 0 && C > 0, "bg_chan_dots3: bad argument");
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 3 * (size_t)C, as_stream(stream)) != hipSuccess) {
+        set_error("bg_chan_dots3: memset failed");
+        return BG_ERR_LAUNCH;
+    }
+    ChanDotsFn fn{p, q, r, C};
+    launch_colreduce<3>(fn, sums, (int64_t)C, rows, 1, C, as_stream(stream));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_bn_tangent_fwd_coefs(const double* sums, double count, const float* mean, const float* rstd, const float* gamma,
+                            float* coefs, float* m12, int C, void* stream) {
+    BG_REQUIRE(sums && mean && rstd && gamma && coefs && m12 && C > 0 && count > 0, "bg_bn_tangent_fwd_coefs: bad argument");
+    hipLaunchKernelGGL(bn_tangent_fwd_coefs_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count,
+                       mean, rstd, gamma, coefs, m12, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_bn_tangent_bwd_coefs(const double* sums, double count, const float* mean, const float* rstd, const float* gamma,
+                            const float* m12, float* coefs_dxd, float* coefs_dx, float* dgamma, int C, void* stream) {
+    BG_REQUIRE(sums && mean && rstd && gamma && m12 && coefs_dxd && coefs_dx && dgamma && C > 0 && count > 0,
+               "bg_bn_tangent_bwd_coefs: bad argument");
+    hipLaunchKernelGGL(bn_tangent_bwd_coefs_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count,
+                       mean, rstd, gamma, m12, coefs_dxd, coefs_dx, dgamma, C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_chan_lincomb3(const float* p, const float* cp, const float* q, const float* cq, const float* r, const float* cr,
+                     const float* c0, float* out, int64_t rows, int C, void* stream) {
+    BG_REQUIRE(p && cp && q && cq && c0 && out && rows > 0 && C > 0 && (!r || cr), "bg_chan_lincomb3: bad argument");
+    const int64_t total = rows * C;
+    hipLaunchKernelGGL(chan_lincomb3_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), p, cp, q, cq, r, cr,
+                       c0, out, total, C);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

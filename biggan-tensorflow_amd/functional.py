@@ -921,6 +921,7 @@ class BnActFn(Function):
             KinkProbe.sites.append((getattr(alpha, "bg_name", None), "bn", x.detach().float().clone(), mean.clone(),
                                     rstd.clone(), gamma_c.detach().clone(), beta_c.detach().clone(), per_sample))
         ctx.x, ctx.mean, ctx.rstd = x, mean, rstd
+        BnActFn.last_stats = (mean, rstd, count)        # (the tangent pass of the gradient penalty reads them: BnTangentFn)
         ctx.gamma, ctx.beta, ctx.alpha = gamma, beta, alpha
         ctx.gamma_c, ctx.beta_c = gamma_c, beta_c
         ctx.per_sample, ctx.count = per_sample, count
@@ -1278,6 +1279,64 @@ class ScaleAddFn(Function):
 # penalty's parameter gradient is the gradient of a directional derivative of D (include/biggan_hip.h, "Gradient
 # penalty").  Linear ops (conv, dense, pooling sums, residual adds) are their own tangent maps.
 # ------------------------------------------------------------------------------------------
+class BnTangentFn(Function):
+    """Forward-mode tangent of training-mode batch norm (ops.py:580-585 inside the gradient penalty, BigGAN.py:717-742):
+    ydot = gamma rstd (xdot - mean(xdot) - xhat mean(xdot xhat)), and its backward w.r.t. xdot, x (through the batch
+    statistics) and gamma - include/biggan_hip.h "Forward-mode tangent of TRAINING-mode batch norm".  ``mean`` / ``rstd``
+    are the statistics the primal pass just computed from the same x; sums are all-reduced under data parallelism."""
+
+    @staticmethod
+    def forward(ctx, xdot, x, gamma, mean, rstd, count, reduce_fn):
+        xdot, x = _c(xdot), _c(x)
+        C = x.shape[-1]
+        rows = x.numel() // C
+        L = lib()
+        dev = x.device
+        sums = torch.empty(3 * C, dtype=torch.float64, device=dev)
+        check(L.bg_chan_dots3(f32(xdot), f32(x), None, hip.ptr(sums), rows, C, stream()))
+        if reduce_fn is not None:
+            reduce_fn(sums)
+        cf = torch.empty(3 * C, dtype=torch.float32, device=dev)
+        m12 = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        check(L.bg_bn_tangent_fwd_coefs(hip.ptr(sums), float(count), f32(mean), f32(rstd), f32(gamma), f32(cf), f32(m12), C,
+                                        stream()))
+        y = torch.empty_like(x)
+        check(L.bg_chan_lincomb3(f32(xdot), f32(cf[:C]), f32(x), f32(cf[C:2 * C]), None, None, f32(cf[2 * C:]), f32(y),
+                                 rows, C, stream()))
+        ctx.saved = (xdot, x, gamma, mean, rstd, m12, float(count), reduce_fn)
+        return y
+
+    @staticmethod
+    def backward(ctx, s_):
+        s_ = _c(s_)
+        xdot, x, gamma, mean, rstd, m12, count, reduce_fn = ctx.saved
+        C = x.shape[-1]
+        rows = x.numel() // C
+        L = lib()
+        dev = x.device
+        sums = torch.empty(3 * C, dtype=torch.float64, device=dev)
+        check(L.bg_chan_dots3(f32(s_), f32(x), f32(xdot), hip.ptr(sums), rows, C, stream()))
+        if reduce_fn is not None:
+            reduce_fn(sums)
+        cd = torch.empty(3 * C, dtype=torch.float32, device=dev)
+        cx = torch.empty(4 * C, dtype=torch.float32, device=dev)
+        dg = torch.empty(C, dtype=torch.float32, device=dev)
+        check(L.bg_bn_tangent_bwd_coefs(hip.ptr(sums), count, f32(mean), f32(rstd), f32(gamma), f32(m12), f32(cd), f32(cx),
+                                        f32(dg), C, stream()))
+        dxdot = dx = None
+        if ctx.needs_input_grad[0]:
+            dxdot = torch.empty_like(x)
+            check(L.bg_chan_lincomb3(f32(s_), f32(cd[:C]), f32(x), f32(cd[C:2 * C]), None, None, f32(cd[2 * C:]),
+                                     f32(dxdot), rows, C, stream()))
+        if ctx.needs_input_grad[1]:
+            dx = torch.empty_like(x)
+            check(L.bg_chan_lincomb3(f32(s_), f32(cx[:C]), f32(x), f32(cx[C:2 * C]), f32(xdot), f32(cx[2 * C:3 * C]),
+                                     f32(cx[3 * C:]), f32(dx), rows, C, stream()))
+        dgam = param_grad(gamma, ctx.needs_input_grad[2], lambda out: out.copy_(dg))
+        ctx.saved = None
+        return dxdot, dx, dgam, None, None, None, None
+
+
 class PReluTangentFn(Function):
     """ydot = xdot * prelu'(x; alpha)."""
 

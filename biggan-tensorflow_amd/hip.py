@@ -147,6 +147,10 @@ SIGNATURES = {
                                     c_int64, _P]),
     "bg_adam_tf_ema_step_dev": (c_int, [_P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int64,
                                         _P]),
+    "bg_chan_dots3": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
+    "bg_bn_tangent_fwd_coefs": (c_int, [_P, c_double, _P, _P, _P, _P, _P, c_int, _P]),
+    "bg_bn_tangent_bwd_coefs": (c_int, [_P, c_double, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "bg_chan_lincomb3": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "bg_gram16_workspace_bytes": (c_size_t, [c_int, c_int]),
     "bg_gram16": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "bg_cast": (c_int, [_P, c_int, _P, c_int, c_int64, _P]),

@@ -90,8 +90,6 @@ class BigGAN(GANBase):
         if self.use_gradient_penalty and self.gradient_penalty_type not in ('wgan-gp', 'wgan-lp', 'dragan'):
             raise ValueError("gradient penalty type %r (BigGAN.py:736-740 knows wgan-gp, wgan-lp, dragan)"
                              % self.gradient_penalty_type)
-        if self.use_gradient_penalty and args.bn_in_d:
-            raise NotImplementedError("gradient penalty with --bn_in_d (the tangent pass of batch norm)")
         self.ld = args.ld
 
         self.activation = args.activation                                              # BigGAN.py:71-83

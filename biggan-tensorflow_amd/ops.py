@@ -701,9 +701,21 @@ def _bn_type(opt, scope):
 
 def bn(x, opt={}, scope='batch_norm'):
     """ops.py:546-561."""
-    if _is_dual(x):
-        raise NotImplementedError("gradient penalty with --bn_in_d: the tangent pass of batch norm is not implemented")
     type, scope = _bn_type(opt, scope)
+    if _is_dual(x):
+        # forward-mode pass of the gradient penalty through a discriminator with --bn_in_d: the primal goes through the
+        # ordinary kernels, WITHOUT moving the population statistics a second time (the penalty's discriminator is one
+        # instantiation in the reference, and pass (1) of model.gradient_penalty already made its update); the tangent
+        # through functional.BnTangentFn with the statistics the primal call just computed
+        if type not in ('bn', 'batch_norm') or not opt["is_training"]:
+            raise NotImplementedError("gradient penalty with --bn_in_d: only training-mode batch_norm has a tangent pass")
+        frozen = dict(opt)
+        frozen["bn"] = dict(opt.get("bn", {}), momentum=1.0)
+        yp = batch_norm(x.p, opt=frozen, scope=scope)
+        mean, rstd, count = Fn.BnActFn.last_stats
+        with variable_scope(scope):
+            gamma = get_variable("gamma", [x.shape[-1]], initializer=S.constant_initializer(1.0))
+        return Dual(yp, Fn.BnTangentFn.apply(x.t, x.p, gamma, mean, rstd, count, _run.reduce_fn))
     if type == 'bn' or type == 'batch_norm':
         return batch_norm(x, opt=opt, scope=scope)
     elif type == 'batch_renorm':

@@ -229,6 +229,23 @@ int bg_spectral_norm_batch_fwd(const BgSnItem* items_dev, int n_items, void* ws,
 int bg_spectral_norm_batch_bwd(const BgSnItem* items_dev, int n_items, const uint64_t* enable_mask,
                                const uint64_t* accumulate_mask, void* ws, size_t ws_bytes, void* stream);
 
+/* Forward-mode tangent of TRAINING-mode batch norm and its backward: the gradient penalty (BigGAN.py:717-742) through a
+ * discriminator with --bn_in_d (ops.py:546-561).  x, xd, s are [rows, C] fp32.
+ *   bg_chan_dots3            sums[0:C] = sum p, [C:2C] = sum p q, [2C:3C] = sum p r (r may be NULL) in fp64 (the caller
+ *                            all-reduces them under data parallelism)
+ *   bg_bn_tangent_fwd_coefs  from sums(p = xd, q = x): coefs[3C] with yd = coefs[0] xd + coefs[1] x + coefs[2] and m12[2C] =
+ *                            (mean(xd) | mean(xd xhat)), kept for the backward
+ *   bg_bn_tangent_bwd_coefs  from sums(p = s, q = x, r = xd), s = dL/dyd: coefs_dxd[3C] (d_xd = . s + . x + .), coefs_dx[4C]
+ *                            (d_x = . s + . x + . xd + .) and dgamma[C]
+ *   bg_chan_lincomb3         out = cp[c] p + cq[c] q (+ cr[c] r) + c0[c] */
+int bg_chan_dots3(const float* p, const float* q, const float* r, double* sums, int64_t rows, int C, void* stream);
+int bg_bn_tangent_fwd_coefs(const double* sums, double count, const float* mean, const float* rstd, const float* gamma,
+                            float* coefs, float* m12, int C, void* stream);
+int bg_bn_tangent_bwd_coefs(const double* sums, double count, const float* mean, const float* rstd, const float* gamma,
+                            const float* m12, float* coefs_dxd, float* coefs_dx, float* dgamma, int C, void* stream);
+int bg_chan_lincomb3(const float* p, const float* cp, const float* q, const float* cq, const float* r, const float* cr,
+                     const float* c0, float* out, int64_t rows, int C, void* stream);
+
 /* Gram matrix out[c1][c2] = sum_r a[r][c1] * a[r][c2] (fp32, [cols][cols]) of a bf16 row-major matrix a[rows][ld]:
  * the ortho-cosine regulariser's W^T W (utils.py:198) from the packed bf16 copy of w / sigma (BgSnItem.pack_p); the caller
  * rescales by sigma^2.  cols % 8 == ld % 8 == 0; ws from bg_gram16_workspace_bytes (split-K slabs). */

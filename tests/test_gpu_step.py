@@ -580,6 +580,19 @@ def test_step_parity_gradient_penalty(gan_type):
     _run_parity(tr, gan, batch)
 
 
+@pytest.mark.parametrize("gan_type", ["wgan-gp", "ra-dragan"])
+def test_step_parity_gradient_penalty_with_bn_in_d(gan_type):
+    """Gradient penalty through a discriminator with --bn_in_d (BigGAN.py:717-742 through ops.py:546-561): the forward-mode
+    pass needs the tangent of TRAINING-mode batch norm - the batch statistics couple the samples - and the D op's backward
+    its derivative w.r.t. x, the tangent and gamma (functional.BnTangentFn; formulas in include/biggan_hip.h).  Penalty
+    value, d_loss and every D gradient against the oracle's double backward; the population statistics move once for the
+    real, the fake and the interpolated batch each."""
+    tr = oracle_trainer(64, 8, 64, 4, gan_type=gan_type, bn_in_d=True)
+    gan = hip_model_like(tr, gan_type=gan_type, bn_in_d="true")
+    batch = RM.synthetic_batch(tr.cfg, 19, 4)
+    _run_parity(tr, gan, batch)
+
+
 def test_step_parity_ch48_non_power_of_two_channels():
     """--ch 48 (the channel arithmetic of BASELINE configs 3-5, ch = 96): 48 / 96 / 192 / 384 / 768 channels give
     ragged GEMM tiles, the generator's attention (d = 12, dv = 48) runs through the fused kernels' zero-padded
