@@ -582,3 +582,45 @@ def test_tf_adam_documented_update_three_steps():
         v = b2 * v + (1 - b2) * g * g
         w = w - lr_t * m / (np.sqrt(v) + eps)
         assert np.allclose(p["w"].detach().numpy(), w, rtol=0, atol=1e-15)
+
+
+def test_batch_norm_tangent_backward_formulas_finite_differences():
+    """The closed forms behind functional.BnTangentFn / bg_bn_tangent_bwd_coefs (gradient penalty through --bn_in_d):
+    T(x, xd, g) = g r (xd - mean xd - xh mean(xd xh)); for s = dL/dT the derivatives w.r.t. xd, g and x (through the
+    batch statistics) written in include/biggan_hip.h, against central differences in float64."""
+    rng = np.random.default_rng(0)
+    n, eps = 50, 1e-5
+    x, xd, s, g = rng.standard_normal(n) * 1.7 + 0.3, rng.standard_normal(n), rng.standard_normal(n), 1.3
+
+    def T(x, xd, g):
+        mu = x.mean()
+        r = 1.0 / np.sqrt(((x - mu) ** 2).mean() + eps)
+        xh = (x - mu) * r
+        return g * r * (xd - xd.mean() - xh * (xd * xh).mean())
+
+    def L(x, xd, g):
+        return float((T(x, xd, g) * s).sum())
+
+    mu = x.mean()
+    r = 1.0 / np.sqrt(((x - mu) ** 2).mean() + eps)
+    xh = (x - mu) * r
+    m1 = xd.mean()
+    u = xd - m1
+    m2 = (u * xh).mean()
+    d_xd = g * r * (s - s.mean() - xh * (s * xh).mean())
+    d_g = (s * r * (u - xh * m2)).sum()
+    w = g * r * r * s
+    Sw, Swu, Swx = w.sum(), (w * u).sum(), (w * xh).sum()
+    d_x = xh * (3 * m2 * Swx - Swu) / n - m2 * w - (Swx / n) * u + m2 * Sw / n
+
+    def fd(f, v, h=1e-6):
+        out = np.zeros_like(v)
+        for i in range(len(v)):
+            vp, vm = v.copy(), v.copy()
+            vp[i] += h
+            vm[i] -= h
+            out[i] = (f(vp) - f(vm)) / (2 * h)
+        return out
+    assert np.abs(d_xd - fd(lambda v: L(x, v, g), xd)).max() < 1e-7
+    assert np.abs(d_x - fd(lambda v: L(v, xd, g), x)).max() < 1e-7
+    assert abs(d_g - (L(x, xd, g + 1e-6) - L(x, xd, g - 1e-6)) / 2e-6) < 1e-7
