@@ -259,6 +259,7 @@ def run_workload(name, B, a, world, rank, note, extra=(), steps=None, warmup=Non
     if graph:
         gan.capture_graphs(B)
     note("model built: %s, batch %d/GPU%s" % (desc, B, " (HIP-graph replay)" if graph else ""))
+    gan.settle_host()                  # (the training loop of main.py does the same: no generation-2 GC pauses mid-run)
     for i in range(warmup):
         gan.train_step(real)
         torch.cuda.synchronize()

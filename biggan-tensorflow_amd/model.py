@@ -956,6 +956,16 @@ class BigGAN(GANBase):
         return torch.rand(B, self.img_size, self.img_size, self.c_dim, device=self.device,
                           generator=self.gen) * 2.0 - 1.0
 
+    @staticmethod
+    def settle_host():
+        """Take the long-lived object graph (variables, arenas, autograd Function classes, ctypes tables: hundreds of
+        thousands of objects) out of Python's cyclic garbage collector: a generation-2 collection that has to traverse it
+        stalls the enqueueing thread for 45-75 ms (measured r02 at iteration 6 of a config-3 run, tools/host_time.py) -
+        under data parallelism every rank waits for the stalled one.  Call after build_model() (and a first iteration)."""
+        import gc
+        gc.collect()
+        gc.freeze()
+
     def train(self, data_fn=None, iterations=None, resume=True):
         """BigGAN.py:1015-1118 training loop (synthetic data unless ``data_fn`` is given): resume from the
         latest checkpoint of ``checkpoint_dir`` if there is one, print the losses every iteration, save
@@ -1000,6 +1010,7 @@ class BigGAN(GANBase):
                 print(" [!] Load failed...")
         start_time = time.time()
         done = 0
+        self.settle_host()
         for epoch in range(start_epoch, self.epoch):
             for idx in range(start_batch_id, self.iterations_per_epoch):
                 if iterations is not None and done >= iterations:
