@@ -243,7 +243,15 @@ def i32(t):
     return ptr(t)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """The current HIP stream of the current device as a void* (torch.cuda.current_stream() builds a Stream object per
+    call: 9 us, 2600 calls per training iteration; the raw getter is 0.3 us)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return c_void_p(_raw_stream(_raw_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

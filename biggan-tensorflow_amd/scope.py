@@ -89,6 +89,7 @@ class VariableStore:
         self.arenas = {}                     # 'generator' / 'discriminator' -> Arena
         self._stack = []                     # [(full_name, reuse)]
         self._counts = {}                    # scope path -> times opened (for default_name uniquifying)
+        self._kids = {}                      # scope path -> paths of the scopes opened directly inside it
         self.frozen = False
         self.sn_pairs = OrderedDict()        # spectrally-normalised weight name -> name of its u vector
         self.reg_shapes = OrderedDict()      # regularised kernel name -> shape (tf regularisation-loss collection)
@@ -124,16 +125,20 @@ class VariableStore:
         cur = self.scope_name
         full = cur + "/" + name_or_scope if cur else name_or_scope
         self._counts[full] = self._counts.get(full, 0) + 1
+        self._kids.setdefault(cur, set()).add(full)
         inherited = self.reuse if reuse is None else reuse
         self._stack.append((full, inherited))
         try:
             yield full
         finally:
             self._stack.pop()
-            pre = full + "/"
-            for k in self._counts:             # TF close_variable_subscopes
-                if k.startswith(pre):
+            # TF close_variable_subscopes: the default-name counters of everything below `full` start over.  (Walks the
+            # sub-scope tree; a scan of every counter with startswith() cost 2.5 ms of host time per iteration.)
+            todo = [full]
+            while todo:
+                for k in self._kids.get(todo.pop(), ()):
                     self._counts[k] = 0
+                    todo.append(k)
 
     # ---- variables ------------------------------------------------------------------------
     def get_variable(self, name, shape, initializer=None, trainable=True, regularizer=None):
