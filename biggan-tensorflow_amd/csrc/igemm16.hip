@@ -868,10 +868,14 @@ __global__ __launch_bounds__(256, 2) void tn16_kernel(const TN16Params p) {
 //   tile t + 2 is issued right after the barrier of iteration t, the wait before that barrier leaves tile t + 1 in
 //   flight (s_waitcnt vmcnt(6): 6 LDS-DMA instructions per wave and tile).  One block per CU (144 KB of LDS).
 // ------------------------------------------------------------------------------------------
-constexpr int TNX_STAGE = 3 * TN16_TILE;            // A image 0 | A image 1 | B image  (48 KB)
-
-template <int MODE>
-__global__ __launch_bounds__(512, 2) void tn16x_kernel(const TN16Params p) {
+// BK = 32 pixels per stage: a stage is 24 KB, the ring 72 KB, and TWO blocks share a CU (the halo-tile NN kernel's lesson: an
+// 8-wave block alone on its CU leaves the matrix pipe idle at every barrier and in its epilogue); BK = 64 is the first form
+// (one block per CU, 144 KB), kept for A/B (BG_TN16X_BK=64).
+template <int MODE, int BK>
+__global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void tn16x_kernel(const TN16Params p) {
+    constexpr int TILE = BK * 256;                      // bytes of one [BK pixels][128 channels] bf16 image
+    constexpr int TNX_STAGE = 3 * TILE;                 // A image 0 | A image 1 | B image
+    constexpr int NJ = BK / 16;                         // LDS-DMA instructions per wave and A image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 stages
 
     const int t = threadIdx.x;
@@ -887,10 +891,10 @@ __global__ __launch_bounds__(512, 2) void tn16x_kernel(const TN16Params p) {
     const int mf0 = tile_m * 256, cb0 = tile_n * 128;
     const int row_begin = zs * p.rows_per_split;
     const int row_end = min(p.M, row_begin + p.rows_per_split);
-    const int nsteps = max(0, (row_end - row_begin + TN16_BK - 1) / TN16_BK);
+    const int nsteps = max(0, (row_end - row_begin + BK - 1) / BK);
 
-    // staging role: A image (w >> 2), pixel rows 16 j + 4 (w & 3) + prow (j = 0..3), channel chunk `ch` of that image;
-    // B: the same rows for j = 2 (w >> 2), 2 (w >> 2) + 1
+    // staging role: A image (w >> 2), pixel rows 16 j + 4 (w & 3) + prow (j < BK / 16), channel chunk `ch` of that image;
+    // B: the same rows for the j's of half (w >> 2)
     const int prow = lane >> 4;
     const int wq = w & 3, ia = w >> 2;
     const int ch = (lane & 15) ^ ((prow << 2) | wq);
@@ -924,13 +928,13 @@ __global__ __launch_bounds__(512, 2) void tn16x_kernel(const TN16Params p) {
     const unsigned ald2 = 2u * (unsigned)g.ld, bld2 = 2u * (unsigned)p.b_ld;
 
     // wave-uniform LDS destinations as scalars (SALU adds per LDS-DMA instead of VALU + readfirstlane)
-    const uint32_t sa0 = __builtin_amdgcn_readfirstlane(lds0 + ia * TN16_TILE + (4 * wq) * 256);
-    const uint32_t sb0 = __builtin_amdgcn_readfirstlane(lds0 + 2 * TN16_TILE + (4 * wq) * 256);
+    const uint32_t sa0 = __builtin_amdgcn_readfirstlane(lds0 + ia * TILE + (4 * wq) * 256);
+    const uint32_t sb0 = __builtin_amdgcn_readfirstlane(lds0 + 2 * TILE + (4 * wq) * 256);
     auto stage = [&](int slot) {
         const uint32_t sa = sa0 + slot * TNX_STAGE;
         const uint32_t sb = sb0 + slot * TNX_STAGE;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int m = m_next + 16 * j;
             unsigned pix = (unsigned)m;
             bool ok = m < a_lim;
@@ -944,12 +948,12 @@ __global__ __launch_bounds__(512, 2) void tn16x_kernel(const TN16Params p) {
             }
             const void* srca = ok ? static_cast<const void*>(abase + (uint64_t)pix * ald2) : zero;
             glds16_asm(srca, sa + j * 16 * 256);
-            if ((j >> 1) == ia) {          // (wave-uniform) this wave's two rows of the B image
+            if (j / (NJ / 2) == ia) {      // (wave-uniform) this wave's share of the B image's rows
                 const void* srcb = m < b_lim ? static_cast<const void*>(bbase + (uint64_t)(unsigned)m * bld2) : zero;
                 glds16_asm(srcb, sb + j * 16 * 256);
             }
         }
-        m_next += TN16_BK;
+        m_next += BK;
     };
 
     f32x16_t acc[2][2];
@@ -967,9 +971,9 @@ __global__ __launch_bounds__(512, 2) void tn16x_kernel(const TN16Params p) {
         const int row = 8 * kblk + 4 * jj + q;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            a_ad[i][jj] = lds0 + (wm >> 1) * TN16_TILE +
+            a_ad[i][jj] = lds0 + (wm >> 1) * TILE +
                           tr16_swz(row, 4 * ((wm & 1) * 2 + i) + 2 * g16 + (pq >> 1)) + 8 * (pq & 1);
-            b_ad[i][jj] = lds0 + 2 * TN16_TILE + tr16_swz(row, 4 * (wn * 2 + i) + 2 * g16 + (pq >> 1)) + 8 * (pq & 1);
+            b_ad[i][jj] = lds0 + 2 * TILE + tr16_swz(row, 4 * (wn * 2 + i) + 2 * g16 + (pq >> 1)) + 8 * (pq & 1);
         }
     }
     auto operand = [&](uint32_t lo_addr, uint32_t hi_addr) {
@@ -984,15 +988,16 @@ __global__ __launch_bounds__(512, 2) void tn16x_kernel(const TN16Params p) {
     auto kstep = [&](int it, auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
         // tile `it` has landed (this wave's part; the barrier extends that to every wave); tile it + 1 stays in flight
-        if (it + 1 < nsteps)
-            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        else
+        if (it + 1 < nsteps) {
+            if (BK == 64) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");      // 3 NJ / 2 DMA per wave and tile
+            else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        } else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (it + 2 < nsteps) stage((SLOT + 2) % 3);      // the slot every wave finished reading before this barrier
         constexpr uint32_t bufoff = (uint32_t)SLOT * (uint32_t)TNX_STAGE;
 #pragma unroll
-        for (int s = 0; s < TN16_BK / 16; ++s) {
+        for (int s = 0; s < BK / 16; ++s) {
             bf16x8_t a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) a[i] = operand(a_ad[i][0] + (bufoff + 4096 * s), a_ad[i][1] + (bufoff + 4096 * s));
@@ -1377,20 +1382,28 @@ int launch_tn16(TN16Params& p, int mode, float* final_out, void* ws, size_t ws_b
             p.slab_stride = sk > 1 ? total : 0;
             p.tiles_m = tm;
             p.tiles_n = tn;
-            constexpr int ldsx = 3 * TNX_STAGE;
+            static const int bk = getenv("BG_TN16X_BK") ? atoi(getenv("BG_TN16X_BK")) : 32;
+            const int ldsx = 3 * 3 * bk * 256;
             static bool attr_x = false;
             if (!attr_x) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16x_kernel<GATHER_CONV>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, ldsx);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16x_kernel<GATHER_PLAIN>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, ldsx);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16x_kernel<GATHER_CONV, 32>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 32 * 256);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16x_kernel<GATHER_PLAIN, 32>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 32 * 256);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16x_kernel<GATHER_CONV, 64>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 64 * 256);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16x_kernel<GATHER_PLAIN, 64>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 64 * 256);
                 attr_x = true;
             }
             dim3 gridx(tm * tn * sk, 1, 1);
-            if (mode == GATHER_CONV)
-                hipLaunchKernelGGL((tn16x_kernel<GATHER_CONV>), gridx, dim3(512), ldsx, s, p);
-            else
-                hipLaunchKernelGGL((tn16x_kernel<GATHER_PLAIN>), gridx, dim3(512), ldsx, s, p);
+            if (mode == GATHER_CONV) {
+                if (bk == 64) hipLaunchKernelGGL((tn16x_kernel<GATHER_CONV, 64>), gridx, dim3(512), ldsx, s, p);
+                else hipLaunchKernelGGL((tn16x_kernel<GATHER_CONV, 32>), gridx, dim3(512), ldsx, s, p);
+            } else {
+                if (bk == 64) hipLaunchKernelGGL((tn16x_kernel<GATHER_PLAIN, 64>), gridx, dim3(512), ldsx, s, p);
+                else hipLaunchKernelGGL((tn16x_kernel<GATHER_PLAIN, 32>), gridx, dim3(512), ldsx, s, p);
+            }
             BG_LAUNCH_CHECK();
             if (sk > 1) {
                 launch_slab_reduce(reinterpret_cast<const float*>(ws), final_out, total, sk, total, s);
