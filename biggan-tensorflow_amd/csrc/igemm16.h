@@ -30,6 +30,8 @@ struct NN16Params {
     int32_t zfold;
     int32_t pow2;           // g.Wq and g.Hq are powers of two: row -> (b, hq, wq) by shifts instead of divisions
     int32_t wq_shift, hq_shift;
+    int32_t posmajor;       // rows enumerate (position, image) instead of (image, position): a 128-row tile then covers one
+                            // or two positions of a small map and walks only the taps that have a source there
 };
 
 struct TN16Params {

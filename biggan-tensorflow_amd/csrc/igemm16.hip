@@ -83,7 +83,9 @@ constexpr int NN16_TAB = 2 * NN16_TAPS * NN16_BM * 4;          // gather tables 
 constexpr int nn16_lds_bytes(int TN) {
     const int stage = (NN16_BM + 32 * TN) * 128;
     const int epi = NN16_BM * (32 * TN + 4) * 4;
-    return (2 * stage + NN16_TAB > epi ? 2 * stage + NN16_TAB : epi) + NN16_BM * 4;   // + output pixel of every row
+    // + output pixel of every row + the tile's tap flags (in the dynamic block on purpose: a static __shared__ variable
+    // moves the stages off their 1 KB alignment, which costs the LDS-DMA writes of the HBM-bound layers ~25 %)
+    return (2 * stage + NN16_TAB > epi ? 2 * stage + NN16_TAB : epi) + NN16_BM * 4 + 16;
 }
 constexpr int NN16_NOSRC = -(1 << 30);                         // table entry of a tap without a source pixel
 
@@ -105,10 +107,19 @@ __device__ __forceinline__ int64_t nn16_src_off(const Gather& g, const RowPos& r
 
 // row of the implicit GEMM -> output pixel of this stride phase (shifts when the phase grid is a power of two: the
 // divisions of decompose_row cost ~90 VALU instructions per row, as much as several K steps of a C = 96 layer)
-template <int MODE>
+template <int MODE, bool PM>
 __device__ __forceinline__ RowPos nn16_row(const NN16Params& p, int m, int ph, int pw) {
-    if (MODE == GATHER_PLAIN || !p.pow2) return decompose_row<MODE>(p.g, m, p.M, ph, pw);
     RowPos r;
+    if (PM) {                                      // image fastest: every row of a tile sits at (nearly) the same position
+        r.valid = m < p.M;
+        const int pos = m / p.g.Nb;
+        r.b = m - pos * p.g.Nb;
+        const int hq = pos / p.g.Wq;
+        r.ho = hq * p.g.pstep + ph;
+        r.wo = (pos - hq * p.g.Wq) * p.g.pstep + pw;
+        return r;
+    }
+    if (MODE == GATHER_PLAIN || !p.pow2) return decompose_row<MODE>(p.g, m, p.M, ph, pw);
     r.valid = m < p.M;
     const int wq = m & (p.g.Wq - 1);
     const int t = m >> p.wq_shift;
@@ -119,7 +130,9 @@ __device__ __forceinline__ RowPos nn16_row(const NN16Params& p, int m, int ph, i
     return r;
 }
 
-template <int TN, int MODE>
+// PM: position-major rows and a K walk over the tile's own taps (NN16Params::posmajor); the image-major form is its own
+// instantiation because the tap bookkeeping costs the short-K launches (1 x 1 convolutions: 3 K steps) 25 %.
+template <int TN, int MODE, bool PM>
 __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
     constexpr int BM = NN16_BM, BN = 32 * TN;
     constexpr int JA = BM / 32, JB = BN / 32;      // LDS-DMA instructions per wave and K step
@@ -158,36 +171,46 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
     }
     const int C8 = p.C >> 3;
     const int ntap = nkh * nkw;
-    const int nsteps_all = (ntap * C8 + 7) >> 3;
-    const int sps = (nsteps_all + p.splitk - 1) / p.splitk;
-    const int it0 = zs * sps;
-    const int nsteps = max(0, min(nsteps_all, it0 + sps) - it0);
 
     // ---- gather tables ----
     // The source pixel of (row, tap) separates into a row part and a column part: tabh[ih][row] = (b Hs + h) Ws and
     // tabw[iw][row] = w (NN16_NOSRC where the tap has no source).  Built once per block; a tap change in the K walk
     // then costs two LDS reads and an add per row instead of the whole gather arithmetic (which made the C = 96
     // layers, where the tap changes every 1.5 K steps, VALU-bound at ~11 VALU instructions per MFMA).
+    // s_any: bit (axis * NN16_TAPS + i) = some row of this tile has a source under tap i of that axis.  Taps without
+    // any are left out of the K walk: the border tiles of a position-major launch (p.posmajor) then cost what their
+    // sources cost, not k x k zero-page tiles.
+    unsigned& s_any = *reinterpret_cast<unsigned*>(smem + nn16_lds_bytes(TN) - 16);
+    if (PM) {
+        if (t == 0) s_any = 0;
+        __syncthreads();
+    }
+    unsigned any_local = 0;
     int* tabh = reinterpret_cast<int*>(smem + 2 * STAGE);
     int* tabw = tabh + NN16_TAPS * BM;
     for (int e = t; e < 2 * NN16_TAPS * BM; e += 256) {
         const int axis = e / (NN16_TAPS * BM), i = (e / BM) % NN16_TAPS, row = e % BM;
-        const RowPos r = nn16_row<MODE>(p, m0 + row, ph, pw);
+        const RowPos r = nn16_row<MODE, PM>(p, m0 + row, ph, pw);
         int v = NN16_NOSRC;
         if (r.valid && i < (axis ? nkw : nkh)) {
             const int kk = (axis ? kw0 : kh0) + i * kstep;
             const int o = axis ? r.wo : r.ho, n = axis ? g.Ws : g.Hs;
             const int src = MODE == GATHER_CONV ? conv_src(o, kk, g.stride, g.pad, g.reflect, n)
                                                 : tconv_src_from_num(o + g.pad - kk, g.stride, n);
-            if (src >= 0) v = axis ? src : (r.b * g.Hs + src) * g.Ws;
+            if (src >= 0) {
+                v = axis ? src : (r.b * g.Hs + src) * g.Ws;
+                any_local |= 1u << (axis * NN16_TAPS + i);
+            }
         }
         tabh[e] = v;
     }
+    if (PM && any_local) atomicOr(&s_any, any_local);
     // output pixel of every row (transposed gathers: rows enumerate a stride phase, possibly of a padded grid), behind
     // everything the epilogue overlays; 0xffffffff = no output
-    unsigned* tabo = reinterpret_cast<unsigned*>(smem + nn16_lds_bytes(TN) - BM * 4);
-    if (MODE == GATHER_TCONV && t < BM) {
-        const RowPos r = nn16_row<MODE>(p, m0 + t, ph, pw);
+    unsigned* tabo = reinterpret_cast<unsigned*>(smem + nn16_lds_bytes(TN) - 16 - BM * 4);
+    constexpr bool use_tabo = MODE == GATHER_TCONV || PM;
+    if (use_tabo && t < BM) {
+        const RowPos r = nn16_row<MODE, PM>(p, m0 + t, ph, pw);
         tabo[t] = (r.valid && r.ho < g.Ho && r.wo < g.Wo) ? (unsigned)((r.b * g.Ho + r.ho) * g.Wo + r.wo) : 0xffffffffu;
     }
 
@@ -201,18 +224,47 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
     const uint32_t lds0 = static_cast<uint32_t>(
         reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem));
 
-    int tidx, c8, ih, iw;
+    __syncthreads();                     // tables (and s_any) complete
+    // PM: taps this tile walks, bit (ih * NN16_TAPS + iw), in the (ih, iw) order of the packed weights
+    unsigned tapmask = 0;
+    if (PM) {
+        const unsigned any = __builtin_amdgcn_readfirstlane(s_any);      // block-uniform: the K loop stays scalar
+        for (int i = 0; i < nkh; ++i)
+            for (int j = 0; j < nkw; ++j)
+                if (((any >> i) & (any >> (NN16_TAPS + j)) & 1u) != 0) tapmask |= 1u << (i * NN16_TAPS + j);
+    }
+    const int nsteps_all = ((PM ? __builtin_popcount(tapmask) : ntap) * C8 + 7) >> 3;
+    const int sps = (nsteps_all + p.splitk - 1) / p.splitk;
+    const int it0 = zs * sps;
+    const int nsteps = max(0, min(nsteps_all, it0 + sps) - it0);
+
+    // K cursor of this lane.  Image-major: tap index tidx = (ih, iw).  PM: rem = the taps from the current one on
+    // (lowest set bit = current).
+    unsigned rem = tapmask;
+    int tidx = 0, c8, ih = 0, iw = 0;
     {
         const int kk = it0 * 8 + cch;
         tidx = kk / C8;
         c8 = kk - tidx * C8;
-        ih = tidx / nkw;
-        iw = tidx - ih * nkw;
+        if (PM) {
+            for (int i = 0; i < tidx && rem; ++i) rem &= rem - 1;
+        } else {
+            ih = tidx / nkw;
+            iw = tidx - ih * nkw;
+        }
     }
     const unsigned char* asrc[JA];       // source of this lane's chunk at channel 0 of the current tap (or the zero page)
     const unsigned char* wsrc[JB];
     auto set_tap = [&]() {
-        const bool kvalid = tidx < ntap;
+        bool kvalid;
+        if (PM) {
+            kvalid = rem != 0;
+            const int bit = kvalid ? __builtin_ctz(rem) : 0;
+            ih = bit / NN16_TAPS;
+            iw = bit % NN16_TAPS;
+        } else {
+            kvalid = tidx < ntap;
+        }
         const int* th = tabh + (ih & (NN16_TAPS - 1)) * BM + rsub;
         const int* tw = tabw + (iw & (NN16_TAPS - 1)) * BM + rsub;
 #pragma unroll
@@ -228,7 +280,6 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
             wsrc[j] = (kvalid & (n < p.N)) ? wt + 2 * (uint64_t)((unsigned)n * (unsigned)p.C) : zero;
         }
     };
-    __syncthreads();                     // tables complete
     set_tap();
 
     // LDS-DMA through glds16_asm: the table reads of set_tap follow the DMA issue in program order, and behind the
@@ -245,10 +296,14 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
         if (c8 >= C8) {
             do {
                 c8 -= C8;
-                ++tidx;
-                if (++iw == nkw) {
-                    iw = 0;
-                    ++ih;
+                if (PM) {
+                    rem &= rem - 1;
+                } else {
+                    ++tidx;
+                    if (++iw == nkw) {
+                        iw = 0;
+                        ++ih;
+                    }
                 }
             } while (c8 >= C8);
             set_tap();
@@ -328,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
         const int m = m0 + row, col = n0 + cc * 8;
         if (m >= p.M || col >= p.N) continue;
         int64_t ooff;
-        if (MODE == GATHER_TCONV) {
+        if (use_tabo) {
             const unsigned op = tabo[row];
             if (op == 0xffffffffu) continue;
             ooff = (int64_t)op * p.out_ld + col;
@@ -1131,13 +1186,57 @@ static int nn16_steps_min(const NN16Params& p, int mode) {
     return (per_axis * per_axis * (p.C >> 3) + 7) >> 3;
 }
 
+// Fraction of the (row, tap) pairs of a launch that have a source pixel: 1 for reflect-padded forward gathers, 16 / 36
+// for the input gradient of a 3 x 3 convolution on the padded 6 x 6 grid of a 4 x 4 map.  Separable per axis.
+static double nn16_axis_fraction(const Gather& g, int mode, int nq, int n_src) {
+    int64_t valid = 0, slots = 0;
+    for (int ph = 0; ph < (mode == GATHER_TCONV ? g.pstep : 1); ++ph) {
+        int k0 = 0, kstep = 1, nk = g.k;
+        if (mode == GATHER_TCONV && g.pstep > 1) {
+            kstep = g.stride;
+            k0 = (ph + g.pad) % g.stride;
+            nk = (g.k - k0 + g.stride - 1) / g.stride;
+        }
+        for (int q = 0; q < nq; ++q) {
+            const int o = q * g.pstep + ph;
+            for (int i = 0; i < nk; ++i) {
+                const int kk = k0 + i * kstep;
+                bool ok;
+                if (mode == GATHER_CONV) {
+                    const int src = o * g.stride + kk - g.pad;
+                    ok = g.reflect || (src >= 0 && src < n_src);
+                } else {
+                    const int hn = o + g.pad - kk;
+                    ok = hn >= 0 && hn % g.stride == 0 && hn / g.stride < n_src;
+                }
+                valid += ok;
+            }
+            slots += nk;
+        }
+    }
+    return slots ? (double)valid / (double)slots : 1.0;
+}
+
+// Position-major rows (NN16Params::posmajor) when at least a tenth of the tap walk would run on the zero page and a
+// 128-row tile covers few positions (BG_NN16_POSMAJOR=0 switches it off; read per call so that a test can compare).
+static double nn16_posmajor_fraction(const NN16Params& p, int mode) {
+    const char* e = getenv("BG_NN16_POSMAJOR");
+    if (e && atoi(e) == 0) return 1.0;
+    const Gather& g = p.g;
+    if (g.k <= 1 || g.Nb < 16 || g.Hq <= 0 || g.Wq <= 0 || (int64_t)g.Hq * g.Wq > 40 * 40) return 1.0;
+    const double f = nn16_axis_fraction(g, mode, g.Hq, g.Hs) * nn16_axis_fraction(g, mode, g.Wq, g.Ws);
+    return f < 0.9 ? f : 1.0;
+}
+
 // Tile width and split-K by a round model: the grid runs in rounds of `slots` co-resident blocks (2 per CU); a block's
 // time is its K steps x (A-side work + one unit per 32 output columns).  Fewer, wider tiles waste padded columns and
 // can leave the last round (or the only one) mostly empty; narrow ones re-read the A tile more often.
 static NN16Plan plan_nn16(const NN16Params& p, int mode, int zdim, bool allow_split) {
     static const int slots = getenv("BG_NN16_SLOTS") ? atoi(getenv("BG_NN16_SLOTS")) : 512;
     const int64_t tm = (p.M + NN16_BM - 1) / NN16_BM;
-    const int steps = nn16_steps_min(p, mode);
+    int steps = nn16_steps_min(p, mode);
+    const double pm = nn16_posmajor_fraction(p, mode);
+    if (pm < 1.0) steps = max(1, (int)(steps * pm + 0.5));       // taps without sources are not walked
     NN16Plan best{4, 1};
     double best_cost = 1e30;
     for (int tn = 4; tn >= 1; --tn) {
@@ -1163,31 +1262,36 @@ size_t nn16_workspace_bytes(const NN16Params& p, int mode, int zdim, int64_t out
     return pl.splitk > 1 ? (size_t)pl.splitk * out_elems * sizeof(float) : 0;
 }
 
-template <int TN, int MODE>
+template <int TN, int MODE, bool PM>
 static int launch_nn16_inst(const NN16Params& p, dim3 grid, hipStream_t s) {
     constexpr int lds = nn16_lds_bytes(TN);
     static bool attr_done = false;          // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!attr_done) {
         if (lds > 49152 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&nn16_kernel<TN, MODE>),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&nn16_kernel<TN, MODE, PM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             set_error("nn16: cannot raise the dynamic LDS limit to %d bytes", lds);
             return BG_ERR_LAUNCH;
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL((nn16_kernel<TN, MODE>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((nn16_kernel<TN, MODE, PM>), grid, dim3(256), lds, s, p);
     return BG_OK;
+}
+
+template <int MODE, bool PM>
+static int launch_nn16_pm(const NN16Params& p, int tn, dim3 grid, hipStream_t s) {
+    switch (tn) {
+        case 1: return launch_nn16_inst<1, MODE, PM>(p, grid, s);
+        case 2: return launch_nn16_inst<2, MODE, PM>(p, grid, s);
+        case 3: return launch_nn16_inst<3, MODE, PM>(p, grid, s);
+        default: return launch_nn16_inst<4, MODE, PM>(p, grid, s);
+    }
 }
 
 template <int MODE>
 static int launch_nn16_mode(const NN16Params& p, int tn, dim3 grid, hipStream_t s) {
-    switch (tn) {
-        case 1: return launch_nn16_inst<1, MODE>(p, grid, s);
-        case 2: return launch_nn16_inst<2, MODE>(p, grid, s);
-        case 3: return launch_nn16_inst<3, MODE>(p, grid, s);
-        default: return launch_nn16_inst<4, MODE>(p, grid, s);
-    }
+    return p.posmajor ? launch_nn16_pm<MODE, true>(p, tn, grid, s) : launch_nn16_pm<MODE, false>(p, tn, grid, s);
 }
 
 // ---- halo-tile form: which launches take it ----
@@ -1277,6 +1381,7 @@ int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, 
         p.wq_shift = __builtin_ctz(p.g.Wq);
         p.hq_shift = __builtin_ctz(p.g.Hq);
     }
+    p.posmajor = nn16_posmajor_fraction(p, mode) < 1.0;
     dim3 grid(p.tiles_m * p.tiles_n, 1, zdim * p.splitk);
     p.zfold = 0;
     if (mode == GATHER_TCONV && zdim > 1 && p.splitk == 1 && p.g.k % p.g.stride == 0) {

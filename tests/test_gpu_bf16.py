@@ -336,6 +336,54 @@ def test_halo_tile_kernel_matches_the_tap_kernel(kind, N, H, Cin, Cout, k, s):
         Fn.set_precision("fp32")
 
 
+@pytest.mark.parametrize("kind,N,H,Cin,Cout,k,s", [("conv", 16, 4, 96, 64, 3, 1), ("conv", 130, 4, 64, 96, 3, 1),
+                                                   ("conv", 32, 8, 160, 72, 3, 1), ("conv", 64, 8, 64, 128, 3, 2),
+                                                   ("conv", 20, 16, 96, 96, 3, 2), ("deconv", 48, 4, 64, 96, 4, 2),
+                                                   ("deconv", 32, 8, 96, 64, 3, 1), ("deconv", 16, 8, 128, 40, 4, 2)])
+def test_position_major_rows_match_the_image_major_walk(kind, N, H, Cin, Cout, k, s):
+    """nn16_kernel with position-major rows (small maps: a tile covers one or two positions and leaves the taps without
+    a source out of its K walk; BG_NN16_POSMAJOR=0 restores image-major rows, where every tile walks all k x k taps):
+    forward and input gradient of reflect-padded convolutions (the gradient runs on the padded grid, whose frame has
+    1 - 3 of 9 taps) and zero-padded transposed convolutions, batch sizes that do not divide the 128-row tile, C = 96 /
+    160 (K steps that straddle taps) - same bf16 results up to the order of the fp32 accumulation, and both within
+    bf16 rounding of float64 on the same bf16 operands."""
+    from biggan_tensorflow_amd import functional as Fn, hip
+    Fn.set_precision("bf16")
+    try:
+        rng = np.random.default_rng(N + H + Cin + Cout + k)
+        x = cu(rng.standard_normal((N, H, H, Cin)), dtype=torch.bfloat16)
+        wshape = (k, k, Cin, Cout) if kind == "conv" else (k, k, Cout, Cin)
+        w0 = rng.standard_normal(wshape) * 0.1
+        outs = []
+        for pm in ("0", "1"):
+            os.environ["BG_NN16_POSMAJOR"] = pm
+            xc = x.clone().requires_grad_(True)
+            w = cu(w0, True)
+            if kind == "conv":
+                y = Fn.Conv2dFn.apply(xc, w, None, s, 1, H // s, H // s, hip.PAD_REFLECT)
+            else:
+                y = Fn.Deconv2dFn.apply(xc, w, None, s, 1, None)
+            g = cu(np.random.default_rng(7).standard_normal(tuple(y.shape)), dtype=torch.bfloat16)
+            y.backward(g)
+            outs.append((f64(y), f64(xc.grad)))
+        assert rel_err(outs[1][0], outs[0][0]) < 1e-3 and rel_err(outs[1][1], outs[0][1]) < 1e-3
+        # float64 on the operands the kernels saw (the packed weight copy is bf16)
+        xt = x.double().cpu().permute(0, 3, 1, 2)
+        wt = torch.tensor(w0, dtype=torch.float32).to(torch.bfloat16).double()
+        xt.requires_grad_(True)
+        if kind == "conv":
+            yr = torch.nn.functional.conv2d(torch.nn.functional.pad(xt, (1, 1, 1, 1), mode="reflect"),
+                                            wt.permute(3, 2, 0, 1), stride=s)
+        else:
+            yr = torch.nn.functional.conv_transpose2d(xt, wt.permute(3, 2, 0, 1), stride=s, padding=(k - s) // 2)
+        yr.backward(g.double().cpu().permute(0, 3, 1, 2))
+        assert rel_err(outs[1][0], yr.detach().permute(0, 2, 3, 1).numpy()) < 6e-3
+        assert rel_err(outs[1][1], xt.grad.permute(0, 2, 3, 1).numpy()) < 6e-3
+    finally:
+        os.environ.pop("BG_NN16_POSMAJOR", None)
+        Fn.set_precision("fp32")
+
+
 @pytest.mark.parametrize("rows,cols,ld", [(9 * 64, 64, 64), (16 * 96, 192, 192), (4608, 384, 384), (200, 24, 120)])
 def test_gram16_from_packed_weights(rows, cols, ld):
     """bg_gram16: W^T W of a bf16 row-major matrix (the regulariser's Gram from the packed copy of w / sigma, also as a
