@@ -18,9 +18,17 @@
 //       own (tap, channel) cursor.  Out-of-image taps, rows >= M, columns >= N and the K tail fetch a zero page.
 //       The epilogue transposes the accumulators through LDS and stores whole 16-byte row segments
 //       (bias, alpha, residual accumulate, bf16 or fp32 output).
+//       PM = true (NN16Params::posmajor): rows enumerate (position, image) and a tile walks only the taps that have a
+//       source at its positions - the frame of a reflect-padded gradient grid, the borders of 4 x 4 / 8 x 8 maps.
+//   nn16h_kernel  the same product for 3 x 3 stride-1 gathers and the phases of 4 x 4 stride-2 transposed gathers on maps
+//       whose sides are multiples of 16: a block owns a 16 x 16 pixel patch, loads its (16 + NT - 1)^2 source pixels per
+//       64-channel chunk ONCE (pixel rows swizzled so that every tap shift reads conflict-free) and streams only the
+//       weight tiles; 8 waves, two blocks per CU.
 //   tn16_kernel  out[(tap, ca)][cb] = sum_pixels A(pixel, tap)[ca] * Bv(pixel)[cb]   (weight gradients)
 //       both tiles stay PIXEL-major in LDS ([64 pixels][128 channels] bf16, chunk-swizzled) and the MFMA operands
 //       are read transposed with ds_read_b64_tr_b16; fp32 split-K slabs over pixel ranges.
+//   tn16x_kernel  the wide form of it: 256 x 128 output tile, 8 waves, v_mfma_f32_32x32x16_bf16, 3-stage LDS ring of
+//       32-pixel stages filled by hand-counted LDS-DMA (s_waitcnt vmcnt(N)), two blocks per CU.
 #include <stdlib.h>
 
 #include "common.h"
