@@ -162,19 +162,25 @@ def resolve_workload(workload, world, scaling="", batch=0):
     return name, B, mode
 
 
-def pmc_traffic(workload):
+def pmc_traffic(workload, B=None):
     """HBM bytes per implicit-GEMM launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    over this same command (profiles/README.md; counters cannot be read from inside the process)."""
+    over this same command (profiles/README.md; counters cannot be read from inside the process): the passes taken at
+    this batch size (`r*_pmc_<workload>_b<B>.json`), or at the workload's own batch (`r*_pmc_<workload>.json`); None when
+    there is no counter run of this batch."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % workload)))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_b%d.json" % (workload, B)))) if B else []
+    if not files and (B is None or B == WORKLOADS[workload][2]):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % workload)))
     if not files:
         return None, None
     with open(files[-1]) as fh:
         d = json.load(fh)
     n = b = 0.0
     for k, e in d.items():
-        if re.search(r"\b((nn|tn)(16)?_kernel|attn(16)?_(fwd|bwd))", k) and "hbm_read_bytes_per_launch" in e:
+        if k == "_summary" or re.search(r"tn_kernel_bf16_tr<2>|tn16x?_kernel<2[,>]", k):
+            continue                                   # (the regulariser's Gram launches are not conv / attention launches)
+        if re.search(r"\b((nn|tn)(16[xh]?)?_kernel|attn(16)?_(fwd|bwd))", k) and "hbm_read_bytes_per_launch" in e:
             n += e["launches"]
             b += e["launches"] * (e["hbm_read_bytes_per_launch"] + e.get("hbm_write_bytes_per_launch", 0.0))
     return (b / n if n else None), os.path.relpath(files[-1], ROOT)
@@ -218,7 +224,7 @@ def roofline_pass(gan, real, nsteps, peak, fpi, B, ms_per_step, workload):
     achieved = alg_fl / (alg_ms * 1e-3) / 1e12 if alg_ms > 0 else 0.0
     dom_tag, dom = max(by_tag.items(), key=lambda kv: kv[1][0]) if by_tag else ("", [0.0, 0.0, 0])
     dom_tf = dom[1] / (dom[0] * 1e-3) / 1e12 if dom[0] > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(workload)
+    traffic, traffic_src = pmc_traffic(workload, B)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
             "traffic_source": traffic_src,

@@ -471,3 +471,43 @@ def test_bench_keeps_the_global_batch_fixed_under_strong_scaling():
     assert bench.resolve_workload("c2", 4) == ("c2", 64, "weak")
     with pytest.raises(SystemExit):
         bench.resolve_workload("c3", 3)
+
+
+def test_pmc_summary_classifies_the_kernel_names_of_this_build():
+    """tools/summarize_pmc.py sorts rocprofv3 kernel names into the GEMM family (whose HBM bytes DESIGN section 5.1 and
+    bench.py's roofline.traffic quote) and its regulariser part by regular expression: the names the current kernels
+    demangle to must land where they belong (a Gram launch `tn16x_kernel<2, 32>` once fell outside the regulariser
+    pattern `tn16x?_kernel<2>`), and the committed summaries must be consistent with their own per-kernel entries."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("summarize_pmc", os.path.join(root, "tools", "summarize_pmc.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    gemm = ["void bg::nn16_kernel<4, 1, true>(bg::NN16Params)", "void bg::nn16_kernel<3, 0, false>(bg::NN16Params)",
+            "void bg::nn16h_kernel<2, 3, 1>(bg::NN16Params)", "void bg::tn16x_kernel<0, 32>(bg::TN16Params)",
+            "void bg::tn16_kernel<0>(bg::TN16Params)", "bg::nn16_slab_reduce_kernel(float const*, void*)",
+            "void bg::reflect_fold_kernel<false>(void const*, void*)", "void bg::attn16_fwd_kernel<2, 3>(bg::A16Geom)",
+            "void bg::nn_kernel<2, 2, 2, 2, true, 1, false, true>(bg::NNParams)", "void bg::tn_kernel<2, 2, 2, 2, 0, true>(bg::TNParams)"]
+    other = ["bg::adam_kernel(float*)", "bg::sn_batch_normalize_kernel(BgSnItem const*, int, char*)",
+             "bg::lincomb_bf16x8_kernel(void)", "void bg::colreduce_kernel<2, 8, bg::BnStatsFnT<bf16>, double>(void)"]
+    for name in gemm:
+        assert re.search(sp.GEMM_FAMILY, name), name
+    for name in other:
+        assert not re.search(sp.GEMM_FAMILY, name), name
+    for name in ["void bg::tn16x_kernel<2, 32>(bg::TN16Params)", "void bg::tn16_kernel<2>(bg::TN16Params)",
+                 "void bg::tn_kernel_bf16_tr<2>(bg::TNParams)",
+                 "void bg::nn_kernel_bf16<2, 2, false, 2, false, true>(bg::NNParams)"]:
+        assert re.search(sp.REGULARISER, name) and re.search(sp.GEMM_FAMILY, name), name
+    assert not re.search(sp.REGULARISER, "void bg::tn16x_kernel<0, 32>(bg::TN16Params)")
+    for fn in ("r02_pmc_c3.json", "r02_pmc_c3_b256.json"):
+        with open(os.path.join(root, "profiles", fn)) as fh:
+            d = json.load(fh)
+        S_ = d["_summary"]
+        tot = lambda f: d[f]["launches"] * (d[f]["hbm_read_bytes_per_launch"] + d[f].get("hbm_write_bytes_per_launch", 0.0))
+        fams = S_["gemm_families"]
+        assert all(re.search(sp.GEMM_FAMILY, f) for f in fams)
+        reg = sum(tot(f) for f in fams if re.search(sp.REGULARISER, f)) / S_["iterations"]
+        assert abs(reg - S_["regulariser_gemm_hbm_bytes_per_iteration"]) < 1e-6 * max(reg, 1.0)
+        allb = sum(tot(f) for f in fams) / S_["iterations"]
+        assert abs(allb - S_["gemm_family_hbm_bytes_per_iteration"]) < 1e-6 * allb
+        assert abs(allb - reg - S_["conv_attention_gemm_hbm_bytes_per_iteration"]) < 1e-6 * allb

@@ -27,11 +27,11 @@ def family(name):
     return m.group(1) if m else name[:80]
 
 
-GEMM_FAMILY = r"\b((nn|tn)(16x?)?_kernel|attn(16)?_|rgb_|thin_|slab_reduce|reflect_fold)"
+GEMM_FAMILY = r"\b((nn|tn)(16[xh]?)?_kernel|attn(16)?_|rgb_|thin_|slab_reduce|reflect_fold)"
 
 
 # the plain GEMMs of the ortho-cosine regulariser (Gram matrices and their gradients: batch-independent, fp32 weights)
-REGULARISER = r"tn_kernel_bf16_tr<2>|nn_kernel_bf16<2, 2, false, 2, false, true>|tn16x?_kernel<2>"
+REGULARISER = r"tn_kernel_bf16_tr<2>|nn_kernel_bf16<2, 2, false, 2, false, true>|tn16x?_kernel<2[,>]"
 
 
 def main():
