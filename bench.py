@@ -180,7 +180,7 @@ def pmc_traffic(workload, B=None):
     for k, e in d.items():
         if k == "_summary" or re.search(r"tn_kernel_bf16_tr<2>|tn16x?_kernel<2[,>]", k):
             continue                                   # (the regulariser's Gram launches are not conv / attention launches)
-        if re.search(r"\b((nn|tn)(16[xh]?)?_kernel|attn(16)?_(fwd|bwd))", k) and "hbm_read_bytes_per_launch" in e:
+        if re.search(r"(\b(nn|tn)(16[xh]?)?_kernel|attn(16)?_(fwd|bwd))", k) and "hbm_read_bytes_per_launch" in e:
             n += e["launches"]
             b += e["launches"] * (e["hbm_read_bytes_per_launch"] + e.get("hbm_write_bytes_per_launch", 0.0))
     return (b / n if n else None), os.path.relpath(files[-1], ROOT)

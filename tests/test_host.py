@@ -487,9 +487,15 @@ def test_pmc_summary_classifies_the_kernel_names_of_this_build():
             "void bg::nn16h_kernel<2, 3, 1>(bg::NN16Params)", "void bg::tn16x_kernel<0, 32>(bg::TN16Params)",
             "void bg::tn16_kernel<0>(bg::TN16Params)", "bg::nn16_slab_reduce_kernel(float const*, void*)",
             "void bg::reflect_fold_kernel<false>(void const*, void*)", "void bg::attn16_fwd_kernel<2, 3>(bg::A16Geom)",
-            "void bg::nn_kernel<2, 2, 2, 2, true, 1, false, true>(bg::NNParams)", "void bg::tn_kernel<2, 2, 2, 2, 0, true>(bg::TNParams)"]
+            "void bg::nn_kernel<2, 2, 2, 2, true, 1, false, true>(bg::NNParams)", "void bg::tn_kernel<2, 2, 2, 2, 0, true>(bg::TNParams)",
+            "bg::nn_slab_reduce_kernel(float const*, float*)", "bg::slab_reduce_kernel(float const*, float*, long, int, long)",
+            "_ZN2bg21attn16_bwd_dkv_kernelILi1ELi2EEEvPKDF16bS2_S2_S2_PKfS4_PDF16bS5_NS_7A16GeomEllllll",
+            "_ZN2bg20attn16_bwd_dq_kernelILi2ELi3EEEvPKDF16bS2_S2_S2_PKfS4_PDF16bNS_7A16GeomEllll",
+            "void bg::attn_bwd_dkv_kernel<16, 1>(float const*)", "bg::rgb_conv_fwd_kernel(float const*)"]
     other = ["bg::adam_kernel(float*)", "bg::sn_batch_normalize_kernel(BgSnItem const*, int, char*)",
-             "bg::lincomb_bf16x8_kernel(void)", "void bg::colreduce_kernel<2, 8, bg::BnStatsFnT<bf16>, double>(void)"]
+             "bg::lincomb_bf16x8_kernel(void)", "void bg::colreduce_kernel<2, 8, bg::BnStatsFnT<bf16>, double>(void)",
+             "_ZN2bg30bn_apply_act_fwd_bf16x8_kernelEPKDF16bPKfS3_S3_S3_iS3_PDF16biii", "bg::bn_finalize_kernel(double const*)",
+             "_ZN2bg16colreduce_kernelILi2ELi8ENS_10BnStatsFnTIDF16bEEdEEvT1_PT2_llii", "bg::ortho_cosine_kernel(float const*)"]
     for name in gemm:
         assert re.search(sp.GEMM_FAMILY, name), name
     for name in other:

@@ -27,7 +27,7 @@ def family(name):
     return m.group(1) if m else name[:80]
 
 
-GEMM_FAMILY = r"\b((nn|tn)(16[xh]?)?_kernel|attn(16)?_|rgb_|thin_|slab_reduce|reflect_fold)"
+GEMM_FAMILY = r"(\b(nn|tn)(16[xh]?)?_kernel|attn(16)?_|\brgb_|\bthin_|slab_reduce|reflect_fold)"
 
 
 # the plain GEMMs of the ortho-cosine regulariser (Gram matrices and their gradients: batch-independent, fp32 weights)
