@@ -517,3 +517,28 @@ def test_pmc_summary_classifies_the_kernel_names_of_this_build():
         allb = sum(tot(f) for f in fams) / S_["iterations"]
         assert abs(allb - S_["gemm_family_hbm_bytes_per_iteration"]) < 1e-6 * allb
         assert abs(allb - reg - S_["conv_attention_gemm_hbm_bytes_per_iteration"]) < 1e-6 * allb
+
+
+def test_workspace_queries_run_the_bf16_planner_on_the_host():
+    """The workspace queries of the bf16-resident convolutions are pure host code and run the same tile / split-K planner
+    as the launch (igemm16.hip plan_nn16, incl. the position-major decision for small maps): with either setting of
+    BG_NN16_POSMAJOR the input-gradient workspace holds at least the gradient on the reflect-padded grid, plus whole
+    fp32 split-K slabs of it."""
+    import ctypes
+    L = hip.lib()
+    try:
+        for (N, H, C, Co, k, s) in [(512, 4, 1536, 1536, 3, 1), (256, 8, 768, 768, 3, 1), (512, 8, 768, 1536, 3, 2),
+                                    (32, 4, 1536, 1536, 3, 1), (8, 4, 96, 96, 3, 1), (2, 128, 96, 96, 3, 1)]:
+            d = hip.conv_desc(N, H, H, C, H // s, H // s, Co, k, s, 1, hip.PAD_REFLECT, hip.COMPUTE_BF16, hip.BF16,
+                              hip.BF16, 1)
+            Hp = ((H // s - 1) * s + k + s - 1) // s * s                  # padded extent, a multiple of the stride
+            padded = N * Hp * Hp * C
+            for pm in ("0", "1"):
+                os.environ["BG_NN16_POSMAJOR"] = pm
+                nb = int(L.bg_conv2d_dgrad_workspace_bytes(ctypes.byref(d)))
+                assert nb >= padded * 2, (N, H, pm, nb)
+                slabs = nb - ((padded * 2 + 255) // 256 * 256)
+                assert slabs % (padded * 4) == 0 and slabs // (padded * 4) <= 16, (N, H, pm, nb)
+                assert int(L.bg_conv2d_fwd_workspace_bytes(ctypes.byref(d))) % (N * (H // s) ** 2 * Co * 4) == 0
+    finally:
+        os.environ.pop("BG_NN16_POSMAJOR", None)
