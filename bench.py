@@ -8,12 +8,14 @@
 One "step" = one D update + one G update (BigGAN.py:1061-1084, n_critic = 1) on a synthetic batch already resident
 in HBM.
 
-  N = 1 (default)  headline = BASELINE config 2 (BigGAN-128, ch 64, batch 64, fp32: the reference's precision), plus a
-                   "target" object: BASELINE config 3 (BigGAN-128, ch 96, bf16) at its GLOBAL batch 256 on this one GPU -
-                   the 1-GPU point of the strong-scaling curve - with its --g_regularization none and --da_policy ""
-                   companions.
-  N > 1            config 3 at FIXED global batch 256 (256 / N images per rank), "scaling": "strong"
-                   (--scaling weak keeps 32 images per rank instead).
+  Every N          the SAME workload: BASELINE config 3 (BigGAN-128, ch 96, bf16 - the north star's target) at its FIXED
+                   global batch 256, 256 / N images per rank, "scaling": "strong" - so the driver's N = 1, 2, 4, 8 lines
+                   are one series.  (--scaling weak keeps 32 images per rank instead.)
+  N = 1 (default)  additionally carries `fp32_config2` (BASELINE config 2: ch 64, batch 64, fp32 - the reference's
+                   precision - with its own roofline), the --g_regularization none / --da_policy "" companions of
+                   SURVEY.md section 8(d), the 32-image share one of 8 ranks runs, and the CPU baseline.
+  `--gpus N` without torchrun's environment starts the N ranks itself (one process per GPU, RCCL) before any GPU call
+  and relays rank 0's line; under `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.
 
 Prints ONE JSON line on rank 0 with the throughput, the MFMA roofline of the convolution / attention GEMM launches
 (timed with HIP events on their stream in a second pass over the same steps; algorithmic FLOPs only - the
@@ -144,19 +146,19 @@ def cpu_baseline(img, ch, sample_batch, steps, note=lambda m: None):
 
 
 def resolve_workload(workload, world, scaling="", batch=0):
-    """(workload name, per-GPU batch, "strong" | "weak") of a run.  One GPU: config 2 unless told otherwise.  N > 1:
-    BASELINE config 3 with its FIXED global batch 256 split into equal shards (strong scaling); --scaling
-    weak keeps the per-GPU batch of the workload table; --batch overrides the per-GPU batch."""
-    name = workload or ("c2" if world == 1 else "c3")
+    """(workload name, per-GPU batch, "strong" | "weak") of a run.  The default workload at EVERY world size is BASELINE
+    config 3 with its FIXED global batch 256 split into equal shards (strong scaling): N = 1 runs all 256
+    images on one GPU, so the driver's N = 1, 2, 4, 8 lines form one series.  --scaling weak keeps the per-GPU batch of
+    the workload table; workloads without a BASELINE global batch (c1, c2, ...) are weak by nature; --batch overrides
+    the per-GPU batch."""
+    name = workload or "c3"
     B = WORKLOADS[name][2]
-    mode = "weak"
-    if world > 1:
-        mode = scaling or ("strong" if name in GLOBAL_BATCH else "weak")
-        if mode == "strong":
-            gb = GLOBAL_BATCH.get(name, B * 8)
-            if gb % world:
-                raise SystemExit("global batch %d is not divisible by %d ranks" % (gb, world))
-            B = gb // world
+    mode = scaling or ("strong" if name in GLOBAL_BATCH else "weak")
+    if mode == "strong":
+        gb = GLOBAL_BATCH.get(name, B * 8)
+        if gb % world:
+            raise SystemExit("global batch %d is not divisible by %d ranks" % (gb, world))
+        B = gb // world
     if batch:
         B = batch
     return name, B, mode
@@ -189,6 +191,59 @@ def pmc_traffic(workload, B=None):
 ALGORITHMIC_TAGS = ("conv2d_", "deconv2d_", "attention")     # launches whose FLOPs SURVEY 8(d) counts
 
 
+def read_prof_dump(path):
+    """Rows of bg_prof_dump (tab-separated: tag, kernel, bytes, flops, ms)."""
+    rows = []
+    with open(path) as fh:
+        next(fh)
+        for line in fh:
+            tag, kernel, nbytes, flops, ms = line.rstrip("\n").split("\t")
+            rows.append((tag, kernel, float(nbytes), float(flops), float(ms)))
+    return rows
+
+
+def roofline_from_rows(rows, nsteps, peak, fpi, B, ms_per_step):
+    """The roofline object of one workload from the per-launch HIP-event records of `nsteps` iterations.
+    achieved = ALGORITHMIC FLOPs of one iteration (4 F_G + 8 F_D per image, SURVEY 8d - padded channels and recomputation
+    are not counted) / the time its conv / transposed-conv / attention launches took; `dominant` = the kernel SYMBOL
+    (what rocprofv3 lists) with the most time among them."""
+    by_kernel = collections.OrderedDict()
+    alg_ms = lib_fl = alg_bytes = all_ms = 0.0
+    n_alg = 0
+    for tag, kernel, nbytes, f, t in rows:
+        all_ms += t
+        if tag.startswith(ALGORITHMIC_TAGS):
+            alg_ms += t
+            lib_fl += f
+            alg_bytes += nbytes
+            n_alg += 1
+            e = by_kernel.setdefault(kernel or tag.split(" ")[0], [0.0, 0.0, 0, 0.0])
+            e[0] += t
+            e[1] += f
+            e[2] += 1
+            e[3] += nbytes
+    step_fl = fpi * B
+    gemm_ms = alg_ms / nsteps if nsteps else 0.0
+    achieved = step_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    dom_k, dom = max(by_kernel.items(), key=lambda kv: kv[1][0]) if by_kernel else ("", [0.0, 0.0, 0, 0.0])
+    dom_tf = dom[1] / (dom[0] * 1e-3) / 1e12 if dom[0] > 0 else 0.0
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4),
+            "kernel": "conv / transposed-conv implicit-GEMM launches (forward, input gradient, weight gradient) and the "
+                      "fused attention: the launches whose FLOPs SURVEY 8(d) counts",
+            "launches_per_step": int(n_alg // max(nsteps, 1)),
+            "gemm_ms_per_step": round(gemm_ms, 3), "step_algorithmic_flops": step_fl,
+            "gemm_flops_per_step_as_launched": lib_fl / max(nsteps, 1),
+            "algorithmic_bytes_per_launch": round(alg_bytes / n_alg, 1) if n_alg else None,
+            "algorithmic_bytes_per_step": alg_bytes / max(nsteps, 1),
+            "all_gemm_family_ms_per_step": round(all_ms / max(nsteps, 1), 3),
+            "dominant": {"kernel": dom_k, "launches_per_step": dom[2] // max(nsteps, 1),
+                         "ms_per_step": round(dom[0] / max(nsteps, 1), 3), "achieved": round(dom_tf, 2),
+                         "frac": round(dom_tf / peak, 4),
+                         "algorithmic_bytes_per_launch": round(dom[3] / dom[2], 1) if dom[2] else None},
+            "step_frac_of_peak": round(step_fl / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
+
+
 def roofline_pass(gan, real, nsteps, peak, fpi, B, ms_per_step, workload):
     """Second pass over the same steps with every GEMM-family launch bracketed by HIP events on its stream."""
     import torch
@@ -199,48 +254,24 @@ def roofline_pass(gan, real, nsteps, peak, fpi, B, ms_per_step, workload):
     for _ in range(nsteps):
         gan.train_step(real)
     torch.cuda.synchronize()
-    fd, path = tempfile.mkstemp(suffix=".csv")
+    fd, path = tempfile.mkstemp(suffix=".tsv")
     os.close(fd)
     L.bg_prof_dump(path.encode())
-    ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-    L.bg_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+    L.bg_prof_reset()
     L.bg_prof_enable(0)
-    by_tag = collections.OrderedDict()
-    alg_ms = alg_fl = all_ms = 0.0
-    with open(path) as fh:
-        next(fh)
-        for line in fh:
-            tag, f, t = line.rsplit(",", 2)
-            f, t = float(f), float(t)
-            all_ms += t
-            if tag.startswith(ALGORITHMIC_TAGS):
-                alg_ms += t
-                alg_fl += f
-                e = by_tag.setdefault(tag, [0.0, 0.0, 0])
-                e[0] += t
-                e[1] += f
-                e[2] += 1
+    rows = read_prof_dump(path)
     os.unlink(path)
-    achieved = alg_fl / (alg_ms * 1e-3) / 1e12 if alg_ms > 0 else 0.0
-    dom_tag, dom = max(by_tag.items(), key=lambda kv: kv[1][0]) if by_tag else ("", [0.0, 0.0, 0])
-    dom_tf = dom[1] / (dom[0] * 1e-3) / 1e12 if dom[0] > 0 else 0.0
+    out = roofline_from_rows(rows, nsteps, peak, fpi, B, ms_per_step)
     traffic, traffic_src = pmc_traffic(workload, B)
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-            "traffic_source": traffic_src,
-            "kernel": "conv / transposed-conv implicit-GEMM launches (forward, input gradient, weight gradient) and the "
-                      "fused attention: the launches whose FLOPs SURVEY 8(d) counts",
-            "launches_per_step": int(sum(e[2] for e in by_tag.values()) // nsteps),
-            "gemm_ms_per_step": round(alg_ms / nsteps, 3), "gemm_flops_per_step": alg_fl / nsteps,
-            "all_gemm_family_ms_per_step": round(all_ms / nsteps, 3),
-            "dominant": {"launch": dom_tag, "launches_per_step": dom[2] // nsteps, "ms_per_step": round(dom[0] / nsteps, 3),
-                         "achieved": round(dom_tf, 2), "frac": round(dom_tf / peak, 4)},
-            "step_algorithmic_flops": fpi * B,
-            "step_frac_of_peak": round(fpi * B / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
+    out["traffic"] = traffic
+    out["traffic_unit"] = "HBM bytes per launch (rocprofv3 --pmc passes of this command; algorithmic_bytes_per_launch beside it)"
+    out["traffic_source"] = traffic_src
+    return out
 
 
 def run_workload(name, B, a, world, rank, note, extra=(), steps=None, warmup=None, roofline=True, graph=False):
     """Build the model for one workload, time `steps` iterations, optionally the roofline pass.  Returns a dict."""
+    import gc
     import torch
     from biggan_tensorflow_amd import main as M, model, scope as S
     img, ch, _, desc = WORKLOADS[name]
@@ -252,7 +283,8 @@ def run_workload(name, B, a, world, rank, note, extra=(), steps=None, warmup=Non
             "--da_policy", kw["da_policy"], "--g_regularization", kw["g_regularization"], "--n_labels", str(a.n_labels),
             "--precision", precision]
     args = M.parse_args(argv, make_dirs=False)
-    peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+    # arithmetic type and peak follow the precision actually run, not the workload's name
+    peak = FP32_MFMA_PEAK_TFLOPS if precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
     gan = model.BigGAN(args, device="cuda", store=S.VariableStore("cuda", seed=42)).build_model()
     real = gan.synthetic_batch(B)
     steps = steps or a.steps
@@ -284,7 +316,7 @@ def run_workload(name, B, a, world, rank, note, extra=(), steps=None, warmup=Non
     note("%s: timed %d steps: %.1f ms/step, %.1f images/sec" % (name, steps, ms_per_step, value))
     fpi, _, _ = step_flops_per_image(img, ch)
     out = {"workload": desc, "img_size": img, "ch": ch, "per_gpu_batch": B, "global_batch": B * world,
-           "precision": precision,
+           "precision": precision, "dtype": "f32" if precision == "fp32" else "bf16",
            "storage_dtype": ("bf16 activations + packed bf16 conv weights; fp32 master weights, optimiser, statistics"
                              if precision == "bf16" else "fp32"),
            "da_policy": kw["da_policy"], "g_regularization": kw["g_regularization"],
@@ -294,21 +326,70 @@ def run_workload(name, B, a, world, rank, note, extra=(), steps=None, warmup=Non
     if roofline and not graph:
         out["roofline"] = roofline_pass(gan, real, min(steps, 3), peak, fpi, B, ms_per_step, name)
         note("%s: roofline pass done" % name)
-    del gan, real
+    del gan, real, losses
+    gc.unfreeze()                      # the frozen object graph of THIS model must be collectable before the next one
+    gc.collect()
     torch.cuda.empty_cache()
     return out
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` outside torchrun: start the N ranks (one process per GPU) through torch.distributed.run BEFORE
+    this process touches a GPU, relay rank 0's JSON line (the children share our stdout) and return the launcher's exit
+    code, non-zero if any rank failed."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("[bench] --gpus %d without WORLD_SIZE: starting %d ranks: %s" % (n, n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(a, rank, world):
+    """--dry_run: the rank plumbing of a run without the model (no GPU needed: gloo) - process group from the
+    environment, workload resolution, the barrier / MAX-over-ranks timing and rank 0's line.  `value` is null: nothing
+    was measured.  tests/test_parallel.py drives `bench.py --gpus 2 --dry_run` through the self-spawning launcher."""
+    import torch
+    name, B, scaling = resolve_workload(a.workload, world, a.scaling, a.batch)
+    img, ch, _, desc = WORKLOADS[name]
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        torch.distributed.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "BigGAN-%d train-step images/sec" % img, "value": None, "unit": "images/sec",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dry_run": True,
+                          "max_over_ranks_s": round(float(dt.item()), 4),
+                          "config": {"workload": desc, "img_size": img, "ch": ch, "per_gpu_batch": B,
+                                     "global_batch": B * world, "parallelism": "dp%d" % world}}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", type=str, default="", choices=[""] + sorted(WORKLOADS),
-                    help="default: c2 on one GPU (+ the config-3 target object), c3 at fixed global batch 256 on N > 1")
+                    help="default: c3 = BASELINE config 3 at its fixed global batch 256 split over the ranks")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--scaling", type=str, default="", choices=["", "strong", "weak"],
-                    help="N > 1: strong (default) = BASELINE's fixed global batch split over the ranks; weak = per-GPU batch fixed")
+                    help="strong (default for c3 / c4 / c5) = BASELINE's fixed global batch split over the ranks; "
+                         "weak = per-GPU batch fixed")
     ap.add_argument("--da_policy", type=str, default="full")
     ap.add_argument("--g_regularization", type=str, default="ortho_cosine")
     ap.add_argument("--n_labels", type=int, default=0, help="class-conditional variant: synthetic one-hot labels")
@@ -318,17 +399,25 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the iteration from captured HIP graphs (N=1 only)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
-    ap.add_argument("--no_target", action="store_true", help="N = 1 default run: skip the config-3 target object")
+    ap.add_argument("--no_companions", action="store_true",
+                    help="N = 1 default run: only the headline (skip fp32_config2, the two SURVEY 8(d) companions and the "
+                         "32-image share)")
+    ap.add_argument("--dry_run", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+
+    if a.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))      # (nothing in this process has touched a GPU yet)
 
     t_start = time.perf_counter()
     import torch
     import biggan_tensorflow_amd  # noqa: F401
     from biggan_tensorflow_amd import parallel
 
-    rank, world, local = parallel.init_from_env()
-    if world != a.gpus and world > 1:
+    rank, world, local = parallel.init_from_env(backend="gloo" if a.dry_run else None)
+    if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.dry_run:
+        return dry_run(a, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     torch.cuda.set_device(local % torch.cuda.device_count())   # (ranks share a card only in gloo rehearsals)
@@ -337,7 +426,7 @@ def main():
         if rank == 0:
             print("[bench %7.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
-    default_run = a.workload == ""
+    default_run = a.workload == "" and not a.batch and not a.scaling and not a.precision
     name, B, scaling = resolve_workload(a.workload, world, a.scaling, a.batch)
     img, ch, _, desc = WORKLOADS[name]
     if a.graph and world != 1:
@@ -345,57 +434,58 @@ def main():
                          "tools/rccl_graph_probe.py aborts)")
     res = run_workload(name, B, a, world, rank, note, roofline=not a.no_roofline, graph=a.graph)
 
-    target = None
-    if default_run and world == 1 and not a.no_target:
-        # BASELINE config 3 (the north-star target) at its global batch on this ONE GPU = the 1-GPU point of the
-        # strong-scaling curve, plus the two companions SURVEY 8(d) asks for
-        note("target: BASELINE config 3 (BigGAN-128 ch=96 bf16) at global batch 256 on one GPU ...")
-        t = run_workload("c3", 256, a, world, rank, note, steps=4, warmup=2, roofline=not a.no_roofline)
-        comp = {}
+    companions = fp32_c2 = per32 = None
+    if default_run and world == 1 and not a.no_companions and not a.graph:
+        # the two companions SURVEY 8(d) asks for, one rank's 32-image share of the 8-GPU run, and BASELINE config 2
+        # (the reference's precision) with its own roofline
+        companions = {}
         for key, extra in (("g_regularization_none", {"g_regularization": "none"}), ("da_policy_empty", {"da_policy": ""})):
-            c = run_workload("c3", 256, a, world, rank, note, extra=extra.items(), steps=3, warmup=1, roofline=False)
-            comp[key] = {"value": c["value"], "ms_per_step": c["ms_per_step"]}
-        per32 = run_workload("c3", 32, a, world, rank, note, steps=6, warmup=2, roofline=False)
-        target = {"metric": "BigGAN-128 ch=96 bf16 train-step images/sec (BASELINE config 3)", "n_gpus": 1,
-                  "value": t["value"], "unit": "images/sec", "ms_per_step": t["ms_per_step"], "global_batch": 256,
-                  "dtype": "bf16", "storage_dtype": t["storage_dtype"], "steps": t["steps"],
-                  "step_frac_of_peak": t["step_frac_of_peak"], "roofline": t.get("roofline"),
-                  "scaling_series": "this object is the N = 1 point of the `--gpus N` strong-scaling series (same workload, "
-                                    "same global batch 256); the headline value above is config 2 in fp32",
-                  "companions": comp, "losses": t["losses"],
-                  "per_gpu_share_32": {"value": per32["value"], "ms_per_step": per32["ms_per_step"],
-                                       "note": "one rank's work of the 8-GPU run (32 images per step), without collectives"}}
+            c = run_workload("c3", B, a, world, rank, note, extra=extra.items(), steps=min(a.steps, 5), warmup=1,
+                             roofline=False)
+            companions[key] = {"value": c["value"], "ms_per_step": c["ms_per_step"]}
+        p32 = run_workload("c3", 32, a, world, rank, note, steps=min(a.steps, 10), warmup=2, roofline=False)
+        per32 = {"value": p32["value"], "ms_per_step": p32["ms_per_step"],
+                 "note": "one rank's work of the 8-GPU run (32 images per step), without collectives"}
+        note("fp32_config2: BASELINE config 2 (BigGAN-128 ch=64 batch=64 fp32) ...")
+        c2 = run_workload("c2", 64, a, world, rank, note, steps=min(a.steps, 10), warmup=2, roofline=not a.no_roofline)
+        fp32_c2 = {"metric": "BigGAN-128 ch=64 batch=64 fp32 train-step images/sec (BASELINE config 2)", "n_gpus": 1,
+                   "value": c2["value"], "unit": "images/sec", "ms_per_step": c2["ms_per_step"], "steps": c2["steps"],
+                   "dtype": "f32", "step_frac_of_peak": c2["step_frac_of_peak"], "roofline": c2.get("roofline"),
+                   "losses": c2["losses"]}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        sb = {64: 32, 128: 8, 256: 2}.get(img, 1)      # ~10-20 s of CPU work on 16 cores
+        sb = {64: 32, 128: 8 if ch <= 64 else 4, 256: 2}.get(img, 1)      # ~10-30 s of CPU work on 16 cores
         note("cpu baseline (oracle, batch %d) ..." % sb)
         cpu = cpu_baseline(img, ch, sb, 2 if img <= 128 else 1, note)
         note("cpu baseline done")
 
     if rank == 0:
-        bf16 = name in BF16_WORKLOADS
         out = {
             "metric": "BigGAN-128 train-step images/sec" if img == 128 else "BigGAN-%d train-step images/sec" % img,
             "value": res["value"], "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": scaling,
-            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
             "config": {"workload": desc, "img_size": img, "ch": ch, "per_gpu_batch": B, "global_batch": B * world,
                        "da_policy": a.da_policy, "g_regularization": a.g_regularization, "n_labels": a.n_labels,
                        "gan_type": a.gan_type, "hip_graph": bool(a.graph), "precision": res["precision"],
                        "storage_dtype": res["storage_dtype"], "parallelism": "dp%d" % world},
-            "losses": res["losses"],
+            "losses": res["losses"], "step_frac_of_peak": res["step_frac_of_peak"],
         }
-        if world > 1 and scaling == "strong":
-            out["config"]["scaling_series"] = ("N = 1 point of this series: the 'target' object of the --gpus 1 line "
-                                               "(this workload at global batch %d on one GPU)" % (B * world))
+        if scaling == "strong":
+            out["config"]["scaling_series"] = ("every --gpus N line of this workload keeps the global batch %d: "
+                                               "N = 1 runs it on one GPU" % (B * world))
         if "roofline" in res:
             out["roofline"] = res["roofline"]
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        if target is not None:
-            out["target"] = target
-        print(json.dumps(out))
+        if companions is not None:
+            out["companions"] = companions
+        if per32 is not None:
+            out["per_gpu_share_32"] = per32
+        if fp32_c2 is not None:
+            out["fp32_config2"] = fp32_c2
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

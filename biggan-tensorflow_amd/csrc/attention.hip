@@ -461,12 +461,14 @@ static bool attn_shape_ok(int N, int Nk, int d, int dv) {
 template <int DQ, int DVT>
 static void launch_fwd(hipStream_t s, const float* q, const float* k, const float* v, float* o, float* lse, int B,
                        int N, int Nk, int d, int dv) {
+    prof_kernel("attn_fwd_kernel<%d, %d>", DQ, DVT);
     hipLaunchKernelGGL((attn_fwd_kernel<DQ, DVT>), dim3(N / 128, B), dim3(256), 0, s, q, k, v, o, lse, N, Nk, d, dv);
 }
 template <int DQ, int DVT>
 static void launch_bwd(hipStream_t s, const float* q, const float* k, const float* v, const float* dout,
                        const float* lse, const float* delta, float* dq, float* dk, float* dvo, int B, int N, int Nk,
                        int d, int dv) {
+    prof_kernel("attn_bwd_dq_kernel + attn_bwd_dkv_kernel<%d, %d>", DQ, DVT);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DQ, DVT>), dim3(N / 128, B), dim3(256), 0, s, q, k, v, dout, lse, delta,
                        dq, N, Nk, d, dv);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DQ, DVT>), dim3(Nk / 128, B), dim3(256), 0, s, q, k, v, dout, lse, delta,

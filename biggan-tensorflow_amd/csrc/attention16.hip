@@ -483,6 +483,7 @@ static bool a16_shape_ok(int N, int Nk, int d, int dv) {
 template <int DQT, int DVT>
 static void a16_launch_fwd(hipStream_t s, const __bf16* q, const __bf16* k, const __bf16* v, __bf16* o, float* lse, int B,
                            const A16Geom& gm) {
+    prof_kernel("attn16_fwd_kernel<%d, %d>", DQT, DVT);
     hipLaunchKernelGGL((attn16_fwd_kernel<DQT, DVT>), dim3(gm.N / 128, B), dim3(256), 0, s, q, k, v, o, lse, gm);
 }
 template <int DQT, int DVT>
@@ -490,6 +491,7 @@ static void a16_launch_bwd(hipStream_t s, const __bf16* q, const __bf16* k, cons
                            const float* lse, const float* delta, __bf16* dq, __bf16* dk, __bf16* dvo, int B,
                            const A16Geom& gm, int64_t ldg, int64_t sg, int64_t lddq, int64_t sdq, int64_t lddk, int64_t sdk,
                            int64_t lddv, int64_t sdv) {
+    prof_kernel(dq ? "attn16_bwd_dq_kernel<%d, %d>" : "attn16_bwd_dkv_kernel<%d, %d>", DQT, DVT);
     if (dq)
         hipLaunchKernelGGL((attn16_bwd_dq_kernel<DQT, DVT>), dim3(gm.N / 128, B), dim3(256), 0, s, q, k, v, dout, lse, delta,
                            dq, gm, ldg, sg, lddq, sdq);
@@ -555,7 +557,8 @@ int bg_attention16_fwd(const BgAttn16Desc* g, const void* q, const void* k, cons
     hipStream_t s = as_stream(stream);
     const A16Geom gm = a16_geom(g);
     const int B = g->B;
-    ProfScope prof(s, 2.0 * B * (double)gm.N * gm.Nk * (gm.d + gm.dv), "attention16_fwd");
+    const double abytes = 2.0 * B * ((double)gm.N * (gm.d + gm.dv) + (double)gm.Nk * (gm.d + gm.dv)) + 4.0 * B * gm.N;
+    ProfScope prof(s, 2.0 * B * (double)gm.N * gm.Nk * (gm.d + gm.dv), "attention16_fwd", abytes);
     A16_DISPATCH(a16_launch_fwd, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)o, lse, B, gm);
     BG_LAUNCH_CHECK();
     return BG_OK;
@@ -581,7 +584,12 @@ int bg_attention16_bwd(const BgAttn16Desc* g, const void* q, const void* k, cons
                            (const __bf16*)dout, delta_ws, B, gm.N, gm.dv, gm.ldo, gm.so, g->ldg, g->sg);
         BG_LAUNCH_CHECK();
     }
-    ProfScope prof(s, 2.0 * B * (double)gm.N * gm.Nk * (2.0 * gm.d + 2.0 * gm.dv), "attention16_bwd");
+    // algorithmic backward work = dV, dP, dQ, dK = 2 x forward over BOTH calls of one backward (the dk / dv call and the
+    // dq call each recompute S; the recomputation is not counted): dk / dv call d + 2 dv, dq call d
+    const double aflops = 2.0 * B * (double)gm.N * gm.Nk * ((dk ? gm.d + 2.0 * gm.dv : 0.0) + (dq ? (double)gm.d : 0.0));
+    const double abytes = 2.0 * B * ((double)gm.N * (gm.d + 2.0 * gm.dv) + (double)gm.Nk * (gm.d + gm.dv)) +
+                          2.0 * B * ((dq ? (double)gm.N * gm.d : 0.0) + (dk ? (double)gm.Nk * (gm.d + gm.dv) : 0.0));
+    ProfScope prof(s, aflops, "attention16_bwd", abytes);
     A16_DISPATCH(a16_launch_bwd, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)dout, lse, delta_ws,
                  (__bf16*)dq, (__bf16*)dk, (__bf16*)dv_out, B, gm, g->ldg, g->sg, g->lddq, g->sdq, g->lddk, g->sdk, g->lddv,
                  g->sdv);

@@ -53,12 +53,21 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh /* >= 4 floats
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// profiling hooks (prof.cpp)
+// profiling hooks (core.hip): HIP events on the launch stream around one C-ABI call of a GEMM-family op.
+//   flops / bytes = the ALGORITHMIC work of the call (each activation once in its stored type,
+//   weights once, weight gradients written once in fp32); prof_kernel() names the kernel instantiation the launcher
+//   chose (what rocprofv3 reports), so that bench.py can group by kernel symbol.
 struct ProfScope {
-    ProfScope(hipStream_t s, double flops, const char* tag = nullptr);
+    ProfScope(hipStream_t s, double flops, const char* tag = nullptr, double bytes = 0.0);
     ~ProfScope();
     hipStream_t stream;
     int slot;
 };
+bool prof_on();
+void prof_kernel(const char* fmt, ...);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: opt in once per (kernel, device).
+// Returns false (with the error string set) when the runtime refuses.
+bool lds_opt_in(const void* fn, int bytes);
 
 }  // namespace bg

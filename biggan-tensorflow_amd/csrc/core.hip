@@ -3,6 +3,7 @@
 #include <stdarg.h>
 
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -20,16 +21,47 @@ void set_error(const char* fmt, ...) {
 
 struct ProfRec {
     hipEvent_t e0, e1;
-    double flops;
+    double flops, bytes;
     char tag[112];
+    char kernel[48];
 };
+static thread_local char g_prof_kernel[48] = "";
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof_recs;     // completed-but-uncollected launches
 static std::vector<ProfRec> g_prof_pool;     // reusable event pairs
 
-ProfScope::ProfScope(hipStream_t s, double flops, const char* tag) : stream(s), slot(-1) {
+bool prof_on() { return g_prof_on; }
+
+void prof_kernel(const char* fmt, ...) {
     if (!g_prof_on) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_prof_kernel, sizeof(g_prof_kernel), fmt, ap);
+    va_end(ap);
+}
+
+// (kernel, device) pairs that already carry the raised dynamic-LDS limit
+static std::mutex g_lds_mu;
+static std::vector<std::pair<const void*, int>> g_lds_done;
+
+bool lds_opt_in(const void* fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lk(g_lds_mu);
+    for (auto& e : g_lds_done)
+        if (e.first == fn && e.second == dev) return true;
+    if (bytes > 49152 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        set_error("cannot raise the dynamic LDS limit of a kernel to %d bytes on device %d", bytes, dev);
+        return false;
+    }
+    g_lds_done.emplace_back(fn, dev);
+    return true;
+}
+
+ProfScope::ProfScope(hipStream_t s, double flops, const char* tag, double bytes) : stream(s), slot(-1) {
+    if (!g_prof_on) return;
+    g_prof_kernel[0] = 0;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
     if (!g_prof_pool.empty()) {
@@ -39,6 +71,8 @@ ProfScope::ProfScope(hipStream_t s, double flops, const char* tag) : stream(s), 
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     }
     r.flops = flops;
+    r.bytes = bytes;
+    r.kernel[0] = 0;
     strncpy(r.tag, tag ? tag : "", sizeof(r.tag) - 1);
     r.tag[sizeof(r.tag) - 1] = 0;
     (void)hipEventRecord(r.e0, s);
@@ -49,7 +83,11 @@ ProfScope::ProfScope(hipStream_t s, double flops, const char* tag) : stream(s), 
 ProfScope::~ProfScope() {
     if (slot < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (slot < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[slot].e1, stream);
+    if (slot < (int)g_prof_recs.size()) {
+        (void)hipEventRecord(g_prof_recs[slot].e1, stream);
+        strncpy(g_prof_recs[slot].kernel, g_prof_kernel, sizeof(g_prof_recs[slot].kernel) - 1);
+        g_prof_recs[slot].kernel[sizeof(g_prof_recs[slot].kernel) - 1] = 0;
+    }
 }
 
 }  // namespace bg
@@ -114,12 +152,12 @@ int bg_prof_dump(const char* path) {
         bg::set_error("bg_prof_dump: cannot open %s", path);
         return BG_ERR_ARG;
     }
-    fprintf(f, "tag,flops,ms\n");
+    fprintf(f, "tag\tkernel\tbytes\tflops\tms\n");     // tab-separated: kernel names carry commas
     for (auto& r : bg::g_prof_recs) {
         if (hipEventSynchronize(r.e1) != hipSuccess) continue;
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) continue;
-        fprintf(f, "%s,%.0f,%.6f\n", r.tag, r.flops, (double)t);
+        fprintf(f, "%s\t%s\t%.0f\t%.0f\t%.6f\n", r.tag, r.kernel, r.bytes, r.flops, (double)t);
     }
     fclose(f);
     return BG_OK;

@@ -669,6 +669,8 @@ static NNPlan plan_nn(int64_t M, int N, int zdim, int niter_min, bool allow_spli
 
 template <int TM, int TN, int WM, int WN, bool BT, int MODE, bool MIRROR>
 static void launch_nn_inst(const NNParams& p, bool vec, dim3 grid, hipStream_t s) {
+    prof_kernel("nn_kernel<%d, %d, %d, %d, %s, %d, %s, %s>", TM, TN, WM, WN, BT ? "true" : "false", MODE,
+                MIRROR ? "true" : "false", vec ? "true" : "false");
     if (vec)
         hipLaunchKernelGGL((nn_kernel<TM, TN, WM, WN, BT, MODE, MIRROR, true>), grid, dim3(256), 0, s, p);
     else
@@ -698,11 +700,14 @@ static void launch_nn_tile(NNParams& p, const NNPlan& pl, bool vec, bool bf16, i
     if constexpr (!BT) {
         static const int nn_btr = getenv("BG_NN_BTR") ? atoi(getenv("BG_NN_BTR")) : 1;   // weights read through ds_read_b64_tr_b16
         if (nn_btr && bf16 && vec && pl.bm == 128 && pl.bn == 128) {
+            prof_kernel("nn_kernel_bf16<2, 2, false, %d, %s, true>", MODE, MIRROR ? "true" : "false");
             hipLaunchKernelGGL((nn_kernel_bf16<2, 2, false, MODE, MIRROR, true>), grid, dim3(256), 0, s, p);
             return;
         }
     }
     if (bf16 && vec && pl.bn >= 64) {
+        prof_kernel("nn_kernel_bf16<%d, %d, %s, %d, %s, false>", pl.bm / 64, pl.bn / 64, BT ? "true" : "false", MODE,
+                    MIRROR ? "true" : "false");
         if (pl.bm == 128 && pl.bn == 128)
             hipLaunchKernelGGL((nn_kernel_bf16<2, 2, BT, MODE, MIRROR>), grid, dim3(256), 0, s, p);
         else if (pl.bm == 128 && pl.bn == 64)
@@ -793,6 +798,8 @@ static size_t tn_workspace_bytes(int Mf, int Cb, int batch, int M) {
 
 template <int TM, int TN, int WM, int WN>
 static void launch_tn_inst(const TNParams& p, int mode, bool vec, dim3 grid, hipStream_t s) {
+    prof_kernel("tn_kernel<%d, %d, %d, %d, %d, %s>", TM, TN, WM, WN, mode == GATHER_PLAIN ? GATHER_PLAIN : GATHER_CONV,
+                vec ? "true" : "false");
     if (mode == GATHER_PLAIN) {
         if (vec)
             hipLaunchKernelGGL((tn_kernel<TM, TN, WM, WN, GATHER_PLAIN, true>), grid, dim3(256), 0, s, p);
@@ -838,6 +845,7 @@ static int launch_tn(TNParams& p, int mode, bool vec, float* final_out, void* ws
     }
     static const int tn_tr = getenv("BG_TN_TR") ? atoi(getenv("BG_TN_TR")) : 1;   // hardware-transposed operand reads (0: VALU transposition)
     if (tn_tr && bf16 && pl.bm == 128 && pl.bn == 128 && p.Ca % 8 == 0 && p.Cb % 8 == 0) {
+        prof_kernel("tn_kernel_bf16_tr<%d>", mode == GATHER_CONV ? GATHER_CONV : GATHER_PLAIN);
         if (mode == GATHER_CONV)
             hipLaunchKernelGGL((tn_kernel_bf16_tr<GATHER_CONV>), grid, dim3(256), 0, s, p);
         else
@@ -845,6 +853,7 @@ static int launch_tn(TNParams& p, int mode, bool vec, float* final_out, void* ws
         BG_LAUNCH_CHECK();
         goto tn_reduce;
     }
+    if (bf16 && pl.bn >= 64) prof_kernel("tn_kernel_bf16<%d, %d, %d>", pl.bm / 64, pl.bn / 64, mode);
     if (bf16 && pl.bn >= 64 && mode == GATHER_CONV) {
         if (pl.bm == 128 && pl.bn == 128)
             hipLaunchKernelGGL((tn_kernel_bf16<2, 2, GATHER_CONV>), grid, dim3(256), 0, s, p);
@@ -913,9 +922,16 @@ static int check_deconv(const BgConvDesc* d) {
 
 struct Tag {
     char s[112];
+    double bytes = 0.0;     // algorithmic HBM bytes of the call: both activation tensors once in their stored type, the
+                            // weights once (2 bytes packed / 4 bytes fp32) or, for a weight gradient, written once in fp32
     Tag(const char* op, const BgConvDesc* d) {
         snprintf(s, sizeof(s), "%s N%d H%d Cin%d Cout%d Ho%d k%d s%d", op, d->N, d->H, d->Cin, d->Cout, d->Ho, d->k,
                  d->stride);
+        const bool wgrad = strstr(op, "wgrad") != nullptr;
+        const double sx = d->x_dtype == BG_BF16 ? 2.0 : 4.0, sy = d->y_dtype == BG_BF16 ? 2.0 : 4.0;
+        const double sw = wgrad ? 4.0 : (d->w_packed ? 2.0 : 4.0);
+        bytes = (double)d->N * d->H * d->W * d->Cin * sx + (double)d->N * d->Ho * d->Wo * d->Cout * sy +
+                (double)d->k * d->k * d->Cin * d->Cout * sw;
     }
     Tag(const char* op, int m, int n, int k) { snprintf(s, sizeof(s), "%s M%d N%d K%d", op, m, n, k); }
     Tag(const char* op, const BgGemmDesc* d) {
@@ -1051,14 +1067,14 @@ int bg_conv2d_fwd(const BgConvDesc* d, const void* x, const void* w, const float
         nn16_from(p, r);
         r.A = x; r.B = w; r.bias = bias; r.alpha = alpha_dev; r.out = y; r.accumulate = accumulate;
         r.out_f32 = d->y_dtype == BG_F32;
-        ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
+        ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s, tag.bytes);
         return launch_nn16(r, GATHER_CONV, 1, (int64_t)r.M * d->Cout, ws, ws_bytes, as_stream(stream));
     }
     BG_REQUIRE(d->y_dtype == BG_F32 && !d->w_packed, "bg_conv2d_fwd: fp32 input needs fp32 weights and output");
     p.A = (const float*)x; p.B = (const float*)w; p.bias = bias; p.alpha = alpha_dev; p.out = (float*)y;
     p.accumulate = accumulate;
     const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
-    ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
+    ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s, tag.bytes);
     return launch_nn(p, GATHER_CONV, false, false, vec, 1, d->k * d->k * kc_of(d->Cin),
                      (int64_t)p.M * d->Cout, true, ws, ws_bytes, as_stream(stream), d->compute == BG_COMPUTE_BF16);
 }
@@ -1094,7 +1110,7 @@ int bg_conv2d_dgrad(const BgConvDesc* d, const void* dy, const void* w, const fl
         r.A = dy; r.B = w; r.alpha = alpha_dev;
         r.out_f32 = d->x_dtype == BG_F32;
         const int64_t out_elems = (int64_t)d->N * r.g.Ho * r.g.Wo * d->Cin;
-        ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
+        ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s, tag.bytes);
         if (!padded) {
             r.out = dx; r.accumulate = accumulate;
             return launch_nn16(r, GATHER_TCONV, d->stride * d->stride, out_elems, ws, ws_bytes, as_stream(stream));
@@ -1116,7 +1132,7 @@ int bg_conv2d_dgrad(const BgConvDesc* d, const void* dy, const void* w, const fl
     conv_dgrad_params(d, p);
     p.A = (const float*)dy; p.B = (const float*)w; p.alpha = alpha_dev; p.out = (float*)dx; p.accumulate = accumulate;
     const bool vec = (d->Cout % 4 == 0) && aligned16(dy) && aligned16(w);
-    ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
+    ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s, tag.bytes);
     return launch_nn(p, GATHER_TCONV, true, p.g.reflect != 0, vec, d->stride * d->stride, tconv_min_iters(d, d->Cout),
                      (int64_t)d->N * d->H * d->W * d->Cin, true, ws, ws_bytes, as_stream(stream),
                      d->compute == BG_COMPUTE_BF16);
@@ -1151,7 +1167,7 @@ int bg_conv2d_wgrad(const BgConvDesc* d, const void* x, const void* dy, float* d
         TN16Params r;
         conv16_wgrad_params(d, r);
         r.A = x; r.Bv = dy;
-        ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
+        ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s, tag.bytes);
         return launch_tn16(r, GATHER_CONV, dw, ws, ws_bytes, as_stream(stream));
     }
     BG_REQUIRE(d->x_dtype == BG_F32 && d->y_dtype == BG_F32, "bg_conv2d_wgrad: x and dy must both be fp32 or both bf16");
@@ -1164,7 +1180,7 @@ int bg_conv2d_wgrad(const BgConvDesc* d, const void* x, const void* dy, float* d
     p.Ca = d->Cin; p.Cb = d->Cout; p.Mf = d->k * d->k * d->Cin; p.b_ld = d->Cout; p.M = d->N * d->Ho * d->Wo;
     p.out_ld = d->Cout; p.batch = 1;
     const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(dy);
-    ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s);
+    ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s, tag.bytes);
     return launch_tn(p, GATHER_CONV, vec, dw, ws, ws_bytes, as_stream(stream), d->compute == BG_COMPUTE_BF16);
 }
 
@@ -1196,7 +1212,7 @@ int bg_deconv2d_fwd(const BgConvDesc* d, const void* x, const void* w, const flo
         nn16_from(p, r);
         r.A = x; r.B = w; r.bias = bias; r.alpha = alpha_dev; r.out = y; r.accumulate = accumulate;
         r.out_f32 = d->y_dtype == BG_F32;
-        ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
+        ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s, tag.bytes);
         return launch_nn16(r, GATHER_TCONV, d->stride * d->stride, (int64_t)d->N * d->Ho * d->Wo * d->Cout, ws, ws_bytes,
                            as_stream(stream));
     }
@@ -1204,7 +1220,7 @@ int bg_deconv2d_fwd(const BgConvDesc* d, const void* x, const void* w, const flo
     p.A = (const float*)x; p.B = (const float*)w; p.bias = bias; p.alpha = alpha_dev; p.out = (float*)y;
     p.accumulate = accumulate;
     const bool vec = (d->Cin % 4 == 0) && aligned16(x) && aligned16(w);
-    ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
+    ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s, tag.bytes);
     return launch_nn(p, GATHER_TCONV, true, false, vec, d->stride * d->stride, tconv_min_iters(d, d->Cin),
                      (int64_t)d->N * d->Ho * d->Wo * d->Cout, true, ws, ws_bytes, as_stream(stream),
                      d->compute == BG_COMPUTE_BF16);
@@ -1236,13 +1252,13 @@ int bg_deconv2d_dgrad(const BgConvDesc* d, const void* dy, const void* w, const 
         nn16_from(p, r);
         r.A = dy; r.B = w; r.alpha = alpha_dev; r.out = dx; r.accumulate = accumulate;
         r.out_f32 = d->x_dtype == BG_F32;
-        ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
+        ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s, tag.bytes);
         return launch_nn16(r, GATHER_CONV, 1, (int64_t)r.M * d->Cin, ws, ws_bytes, as_stream(stream));
     }
     BG_REQUIRE(d->x_dtype == BG_F32 && d->y_dtype == BG_F32 && !d->w_packed, "bg_deconv2d_dgrad: unsupported dtype mix");
     p.A = (const float*)dy; p.B = (const float*)w; p.alpha = alpha_dev; p.out = (float*)dx; p.accumulate = accumulate;
     const bool vec = (d->Cout % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy) && aligned16(w);
-    ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
+    ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s, tag.bytes);
     return launch_nn(p, GATHER_CONV, false, false, vec, 1, d->k * d->k * kc_of(d->Cout),
                      (int64_t)p.M * d->Cin, true, ws, ws_bytes, as_stream(stream), d->compute == BG_COMPUTE_BF16);
 }
@@ -1277,7 +1293,7 @@ int bg_deconv2d_wgrad(const BgConvDesc* d, const void* x, const void* dy, float*
         TN16Params r;
         deconv16_wgrad_params(d, r);
         r.A = dy; r.Bv = x;
-        ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
+        ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s, tag.bytes);
         return launch_tn16(r, GATHER_CONV, dw, ws, ws_bytes, as_stream(stream));
     }
     BG_REQUIRE(d->x_dtype == BG_F32 && d->y_dtype == BG_F32, "bg_deconv2d_wgrad: x and dy must both be fp32 or both bf16");
@@ -1290,7 +1306,7 @@ int bg_deconv2d_wgrad(const BgConvDesc* d, const void* x, const void* dy, float*
     p.Ca = d->Cout; p.Cb = d->Cin; p.Mf = d->k * d->k * d->Cout; p.b_ld = d->Cin; p.M = d->N * d->H * d->W;
     p.out_ld = d->Cin; p.batch = 1;
     const bool vec = (d->Cout % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy) && aligned16(x);
-    ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s);
+    ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s, tag.bytes);
     return launch_tn(p, GATHER_CONV, vec, dw, ws, ws_bytes, as_stream(stream), d->compute == BG_COMPUTE_BF16);
 }
 

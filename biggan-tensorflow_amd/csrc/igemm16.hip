@@ -1273,16 +1273,9 @@ size_t nn16_workspace_bytes(const NN16Params& p, int mode, int zdim, int64_t out
 template <int TN, int MODE, bool PM>
 static int launch_nn16_inst(const NN16Params& p, dim3 grid, hipStream_t s) {
     constexpr int lds = nn16_lds_bytes(TN);
-    static bool attr_done = false;          // > 64 KB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_done) {
-        if (lds > 49152 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&nn16_kernel<TN, MODE, PM>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            set_error("nn16: cannot raise the dynamic LDS limit to %d bytes", lds);
-            return BG_ERR_LAUNCH;
-        }
-        attr_done = true;
-    }
+    // > 48 KB of dynamic LDS needs the opt-in once per kernel and device
+    if (!lds_opt_in(reinterpret_cast<const void*>(&nn16_kernel<TN, MODE, PM>), lds)) return BG_ERR_LAUNCH;
+    prof_kernel("nn16_kernel<%d, %d, %s>", TN, MODE, PM ? "true" : "false");
     hipLaunchKernelGGL((nn16_kernel<TN, MODE, PM>), grid, dim3(256), lds, s, p);
     return BG_OK;
 }
@@ -1322,15 +1315,8 @@ static int nn16h_taps(const NN16Params& p, int mode, int zdim) {
 template <int NT, int NF, int MODE>
 static int launch_nn16h_inst(const NN16Params& p, int blocks, hipStream_t s) {
     constexpr int lds = nn16h_lds_bytes<NT, NF>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nn16h_kernel<NT, NF, MODE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            set_error("nn16h: cannot raise the dynamic LDS limit to %d bytes", lds);
-            return BG_ERR_LAUNCH;
-        }
-        attr_done = true;
-    }
+    if (!lds_opt_in(reinterpret_cast<const void*>(&nn16h_kernel<NT, NF, MODE>), lds)) return BG_ERR_LAUNCH;
+    prof_kernel("nn16h_kernel<%d, %d, %d>", NT, NF, MODE);
     hipLaunchKernelGGL((nn16h_kernel<NT, NF, MODE>), dim3(blocks), dim3(512), lds, s, p);
     return BG_OK;
 }
@@ -1497,18 +1483,13 @@ int launch_tn16(TN16Params& p, int mode, float* final_out, void* ws, size_t ws_b
             p.tiles_n = tn;
             static const int bk = getenv("BG_TN16X_BK") ? atoi(getenv("BG_TN16X_BK")) : 32;
             const int ldsx = 3 * 3 * bk * 256;
-            static bool attr_x = false;
-            if (!attr_x) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16x_kernel<GATHER_CONV, 32>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 32 * 256);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16x_kernel<GATHER_PLAIN, 32>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 32 * 256);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16x_kernel<GATHER_CONV, 64>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 64 * 256);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16x_kernel<GATHER_PLAIN, 64>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 64 * 256);
-                attr_x = true;
-            }
+            const void* fx = mode == GATHER_CONV
+                                 ? (bk == 64 ? reinterpret_cast<const void*>(&tn16x_kernel<GATHER_CONV, 64>)
+                                             : reinterpret_cast<const void*>(&tn16x_kernel<GATHER_CONV, 32>))
+                                 : (bk == 64 ? reinterpret_cast<const void*>(&tn16x_kernel<GATHER_PLAIN, 64>)
+                                             : reinterpret_cast<const void*>(&tn16x_kernel<GATHER_PLAIN, 32>));
+            if (!lds_opt_in(fx, ldsx)) return BG_ERR_LAUNCH;
+            prof_kernel("tn16x_kernel<%d, %d>", mode == GATHER_CONV ? GATHER_CONV : GATHER_PLAIN, bk == 64 ? 64 : 32);
             dim3 gridx(tm * tn * sk, 1, 1);
             if (mode == GATHER_CONV) {
                 if (bk == 64) hipLaunchKernelGGL((tn16x_kernel<GATHER_CONV, 64>), gridx, dim3(512), ldsx, s, p);
@@ -1527,14 +1508,10 @@ int launch_tn16(TN16Params& p, int mode, float* final_out, void* ws, size_t ws_b
     }
     dim3 grid(p.tiles_m * p.tiles_n * p.splitk, 1, 1);
     constexpr int lds = 4 * TN16_TILE;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16_kernel<GATHER_CONV>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn16_kernel<GATHER_PLAIN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    if (!lds_opt_in(mode == GATHER_CONV ? reinterpret_cast<const void*>(&tn16_kernel<GATHER_CONV>)
+                                        : reinterpret_cast<const void*>(&tn16_kernel<GATHER_PLAIN>), lds))
+        return BG_ERR_LAUNCH;
+    prof_kernel("tn16_kernel<%d>", mode == GATHER_CONV ? GATHER_CONV : GATHER_PLAIN);
     if (mode == GATHER_CONV)
         hipLaunchKernelGGL((tn16_kernel<GATHER_CONV>), grid, dim3(256), lds, s, p);
     else

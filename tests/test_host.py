@@ -456,14 +456,15 @@ def test_reference_names_of_the_boundary_exist_with_reference_signatures():
 
 
 def test_bench_keeps_the_global_batch_fixed_under_strong_scaling():
-    """bench.py --gpus N (SURVEY 8e, BASELINE config 3): the global batch stays 256 for N = 2, 4, 8 (strong scaling);
-    one GPU defaults to config 2; --scaling weak keeps 32 images per rank."""
+    """bench.py --gpus N (BASELINE config 3): the global batch stays 256 for N = 1, 2, 4, 8 (strong scaling:
+    one series, N = 1 runs all 256 images on one GPU); --scaling weak keeps 32 images per rank."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    assert bench.resolve_workload("", 1) == ("c2", 64, "weak")
-    for n in (2, 4, 8):
+    assert bench.resolve_workload("", 1) == ("c3", 256, "strong")
+    assert bench.resolve_workload("c2", 1) == ("c2", 64, "weak")
+    for n in (1, 2, 4, 8):
         name, b, mode = bench.resolve_workload("", n)
         assert (name, mode) == ("c3", "strong") and b * n == 256
     assert bench.resolve_workload("", 8, "weak") == ("c3", 32, "weak")
@@ -471,6 +472,28 @@ def test_bench_keeps_the_global_batch_fixed_under_strong_scaling():
     assert bench.resolve_workload("c2", 4) == ("c2", 64, "weak")
     with pytest.raises(SystemExit):
         bench.resolve_workload("c3", 3)
+
+
+def test_bench_roofline_groups_by_kernel_symbol_and_counts_algorithmic_flops():
+    """roofline_from_rows (bench.py): `dominant` is the kernel SYMBOL with the most time (not the per-shape tag: every
+    attention launch shares a tag, every conv shape has its own), `achieved` comes from the step's algorithmic FLOPs
+    (4 F_G + 8 F_D per image), not from what the launches counted (padded channels), and the algorithmic bytes of the
+    launches stand beside the traffic."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows = [("conv2d_fwd N2 H8 Cin8 Cout8 Ho8 k3 s1", "nn16_kernel<4, 0, false>", 1000.0, 4e9, 1.0),
+            ("conv2d_dgrad N2 H8 Cin8 Cout8 Ho8 k3 s1", "nn16_kernel<4, 0, false>", 1000.0, 4e9, 1.5),
+            ("attention16_fwd", "attn16_fwd_kernel<1, 2>", 500.0, 2e9, 2.0),
+            ("deconv2d_wgrad N2 H8 Cin8 Cout8 Ho16 k4 s2", "tn16x_kernel<0, 32>", 3000.0, 6e9, 1.0),
+            ("gram16 M8 N8 K8", "tn16x_kernel<2, 32>", 0.0, 9e9, 7.0)]          # (not an algorithmic launch)
+    r = bench.roofline_from_rows(rows, nsteps=1, peak=100.0, fpi=5e9, B=2, ms_per_step=10.0)
+    assert r["dominant"]["kernel"] == "nn16_kernel<4, 0, false>" and r["dominant"]["ms_per_step"] == 2.5
+    assert r["gemm_ms_per_step"] == 5.5 and r["launches_per_step"] == 4
+    assert abs(r["achieved"] - 1e10 / 5.5e-3 / 1e12) < 1e-2 and r["step_algorithmic_flops"] == 1e10
+    assert r["gemm_flops_per_step_as_launched"] == 1.6e10
+    assert r["algorithmic_bytes_per_step"] == 5500.0 and r["all_gemm_family_ms_per_step"] == 12.5
 
 
 def test_pmc_summary_classifies_the_kernel_names_of_this_build():

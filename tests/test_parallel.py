@@ -79,6 +79,29 @@ def test_gloo_world2_allreduce_and_sharding():
     assert res[0][7] == res[1][7]                      # the same owner map on every rank
 
 
+def test_bench_gpus_n_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` WITHOUT torchrun's environment (how the driver calls it) must run 2 ranks, not one:
+    the launcher spawns them before touching a GPU and relays rank 0's line.  --dry_run = rank plumbing only (gloo, no
+    model, value null) so this runs on the CPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry_run"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 256
+    assert d["config"]["per_gpu_batch"] == 128 and d["config"]["parallelism"] == "dp2" and d["dry_run"] is True
+    # a failing rank makes the launcher exit non-zero
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--dry_run"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0                      # 256 is not divisible by 3 ranks
+
+
 def test_shard_batch_rejects_ragged():
     with pytest.raises(ValueError):
         parallel.shard_batch(65, 0, 2)
