@@ -218,12 +218,6 @@ class Conv2dFn(Function):
     fp32 x: the fp32-tensor kernels (fp32 or bf16 MFMA per Precision.compute), fp32 y.
     bf16 x: the bf16-resident kernels (packed weights, csrc/igemm16.hip); y is bf16 unless ``out_dtype`` says fp32."""
 
-    # The direct kernels for <= 4 INPUT channels (bg_thinconv_*) are correct but, as measured in round 1
-    # (128 x 128 x 3 -> 64, stride 2, batch 128: fwd 251 us / dgrad 1489 us / wgrad 210 us), slower than the
-    # padded implicit GEMM (130 / 411 / 112 us): one pixel per thread iteration leaves them latency-bound.
-    # Off until they process several pixels per iteration; tests switch them on to keep them covered.
-    use_thin = False
-
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad_lo, Ho, Wo, pad_mode, out_dtype=None):
         x = _c(x)
@@ -245,7 +239,7 @@ class Conv2dFn(Function):
             ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, d, x.device)
             pt = weight_packs(pad_channels(w, 8, torch.float32, axis=2, mode=hip.PAD_DUP))[1]
             check(L.bg_conv2d_fwd(d, act(x8), act(pt), f32(bias), None, act(y), 0, f32(ws), nb, stream()))
-            ctx.desc, ctx.rgb, ctx.thin = d, False, False
+            ctx.desc, ctx.rgb = d, False
             ctx.x, ctx.w, ctx.bias = x8, w, bias
             return y
         if ctx.pad8 == "out":
@@ -258,7 +252,7 @@ class Conv2dFn(Function):
             ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, d, x.device)
             pt = weight_packs(pad_channels(w, 8, torch.float32, axis=3, mode=hip.PAD_SPLIT))[1]
             check(L.bg_conv2d_fwd(d, act(x), act(pt), f32(b8), None, act(y8), 0, f32(ws), nb, stream()))
-            ctx.desc, ctx.rgb, ctx.thin = d, False, False
+            ctx.desc, ctx.rgb = d, False
             ctx.x, ctx.w, ctx.bias = x, w, bias
             return pad_channels(y8, Cout, ydt, mode=hip.PAD_FOLD)
         if x.dtype == BF16 and not ctx.resident:
@@ -270,18 +264,15 @@ class Conv2dFn(Function):
             y = torch.empty((N, Ho, Wo, Cout), dtype=ydt, device=x.device)
             ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, d, x.device)
             check(L.bg_conv2d_fwd(d, act(x), act(weight_packs(w)[1]), f32(bias), None, act(y), 0, f32(ws), nb, stream()))
-            ctx.desc, ctx.rgb, ctx.thin = d, False, False
+            ctx.desc, ctx.rgb = d, False
             ctx.x, ctx.w, ctx.bias = x, w, bias
             return y
         w = _c(w)
         d = hip.conv_desc(N, H, W_, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode, Precision.compute)
         y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         ctx.rgb = bool(L.bg_rgbconv_supported(d))      # <= 3 output channels: direct HBM-bound kernels
-        ctx.thin = Conv2dFn.use_thin and (not ctx.rgb) and bool(L.bg_thinconv_supported(d))
         if ctx.rgb:
             check(L.bg_rgbconv_fwd(d, f32(x), f32(w), f32(bias), f32(y), 0, stream()))
-        elif ctx.thin:
-            check(L.bg_thinconv_fwd(d, f32(x), f32(w), f32(bias), f32(y), stream()))
         else:
             ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, d, x.device)
             check(L.bg_conv2d_fwd(d, f32(x), f32(w), f32(bias), None, f32(y), 0, f32(ws), nb, stream()))
@@ -358,8 +349,6 @@ class Conv2dFn(Function):
             dx = torch.empty_like(x)
             if ctx.rgb:
                 check(L.bg_rgbconv_dgrad(d, f32(dy), f32(w), f32(dx), 0, stream()))
-            elif ctx.thin:
-                check(L.bg_thinconv_dgrad(d, f32(dy), f32(w), f32(dx), stream()))
             else:
                 ws, nb = hip.scratch(L.bg_conv2d_dgrad_workspace_bytes, d, x.device)
                 check(L.bg_conv2d_dgrad(d, f32(dy), f32(w), None, f32(dx), 0, f32(ws), nb, stream()))
@@ -369,11 +358,6 @@ class Conv2dFn(Function):
                 nb = L.bg_rgbconv_wgrad_workspace_bytes(d)
                 ws = workspace(nb, x.device)
                 check(L.bg_rgbconv_wgrad(d, f32(x), f32(dy), f32(out), f32(ws), nb, stream()))
-                return
-            if ctx.thin:
-                nb = L.bg_thinconv_wgrad_workspace_bytes(d)
-                ws = workspace(nb, x.device)
-                check(L.bg_thinconv_wgrad(d, f32(x), f32(dy), f32(out), f32(ws), nb, stream()))
                 return
             nb = L.bg_conv2d_wgrad_workspace_bytes(d)
             ws = workspace(nb, x.device)

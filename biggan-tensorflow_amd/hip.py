@@ -74,11 +74,6 @@ SIGNATURES = {
     "bg_rgbconv_dgrad": (c_int, [_CD, _P, _P, _P, c_int, _P]),
     "bg_rgbconv_wgrad_workspace_bytes": (c_size_t, [_CD]),
     "bg_rgbconv_wgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
-    "bg_thinconv_supported": (c_int, [_CD]),
-    "bg_thinconv_fwd": (c_int, [_CD, _P, _P, _P, _P, _P]),
-    "bg_thinconv_dgrad": (c_int, [_CD, _P, _P, _P, _P]),
-    "bg_thinconv_wgrad_workspace_bytes": (c_size_t, [_CD]),
-    "bg_thinconv_wgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
     "bg_gemm_workspace_bytes": (c_size_t, [_GD]),
     "bg_gemm": (c_int, [_GD, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "bg_attention2_supported": (c_int, [c_int, c_int, c_int, c_int]),

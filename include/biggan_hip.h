@@ -118,16 +118,6 @@ size_t bg_rgbconv_wgrad_workspace_bytes(const BgConvDesc*);
 int bg_rgbconv_wgrad(const BgConvDesc*, const float* x, const float* dy, float* dw,
                      void* ws, size_t ws_bytes, void* stream);
 
-/* Direct kernels for 3 x 3 convolutions with <= 4 INPUT channels (the discriminator's first layer on the
- * image, ops.py:293-313: [B,S,S,3] -> ch, stride 2, reflect or zero padding).  Same tensors and layouts as
- * bg_conv2d_*; Cout % 4 == 0, 16 <= Cout <= 1024, stride 1 or 2, pad_lo <= 1.  HBM-bound streams. */
-int bg_thinconv_supported(const BgConvDesc*);
-int bg_thinconv_fwd(const BgConvDesc*, const float* x, const float* w, const float* bias, float* y, void* stream);
-int bg_thinconv_dgrad(const BgConvDesc*, const float* dy, const float* w, float* dx, void* stream);
-size_t bg_thinconv_wgrad_workspace_bytes(const BgConvDesc*);
-int bg_thinconv_wgrad(const BgConvDesc*, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
-                      void* stream);
-
 /* --------------------------------------------------------------------------------------------
  * Plain (batched) matrix products: tf.matmul call sites ops.py:163-165 (dense), 481,485
  * (attention), utils.py:198,222 (Gram matrix of the regulariser).

@@ -60,7 +60,7 @@ CONV_CASES = [
     (3, 4, 32, 1, 3, 1, 1, False),      # single output channel, 4x4 map (all-border reflect)
     (2, 64, 16, 2, 1, 1, 0, False),     # 1x1, two output channels
     (64, 4, 1024, 1024, 3, 1, 1, False),  # small output, long K: split-K slabs
-    (3, 16, 3, 64, 3, 2, 1, False),     # image layer, direct kernels (thinconv): stride 2, reflect
+    (3, 16, 3, 64, 3, 2, 1, False),     # image layer (3 input channels): stride 2, reflect
     (2, 12, 3, 96, 3, 2, 1, True),      # ch = 96: 24 threads per pixel, bias
     (2, 10, 3, 32, 3, 1, 1, False),     # stride 1: both mirrored borders
     (2, 8, 4, 16, 3, 2, 1, False),      # 4 input channels
@@ -133,7 +133,7 @@ def test_conv_zero_padding_same():
 @pytest.mark.parametrize("H,s", [(8, 2), (9, 2), (8, 1)])
 def test_thin_input_conv_zero_padding_tf_same(H, s):
     """Image layer with --conv_padding zero: TF 'SAME' (pad_lo = total // 2, asymmetric for even H at
-    stride 2) through the direct <= 4-input-channel kernels."""
+    stride 2) through the implicit-GEMM kernels with a 3-channel input."""
     Fn, hip = _fn(), _hip()
     rng = np.random.default_rng(H + s)
     x = rng.standard_normal((2, H, H, 3))
@@ -147,14 +147,8 @@ def test_thin_input_conv_zero_padding_tf_same(H, s):
     g = rng.standard_normal(tuple(yr.shape))
     yr.backward(torch.tensor(g))
     xc, wc = cu(x, True), cu(w, True)
-    d = hip.conv_desc(2, H, H, 3, out, out, 32, 3, s, lo, hip.PAD_ZERO)
-    assert hip.lib().bg_thinconv_supported(d)
-    Fn.Conv2dFn.use_thin = True
-    try:
-        y = Fn.Conv2dFn.apply(xc, wc, None, s, lo, out, out, hip.PAD_ZERO)
-        y.backward(cu(g))
-    finally:
-        Fn.Conv2dFn.use_thin = False
+    y = Fn.Conv2dFn.apply(xc, wc, None, s, lo, out, out, hip.PAD_ZERO)
+    y.backward(cu(g))
     assert rel_err(t2n(y), yr.detach().numpy()) < TOL
     assert rel_err(t2n(xc.grad), xt.grad.numpy()) < TOL
     assert rel_err(t2n(wc.grad), wt.grad.numpy()) < TOL
