@@ -438,9 +438,32 @@ class BigGAN(GANBase):
                                 pass
                     self.sn_batches.setdefault(group, []).append(Fn.SnBatch(pairs[i:i + 256], groups))
         self.reg_owner = self._shard_regularisers()
+        self._setup_exchange()
         self.counter = 0
         self.built = True
         return self
+
+    def _setup_exchange(self):
+        """Data parallelism: the process group of the large gradient / parameter exchanges (its own RCCL communicator
+        and stream, parallel.new_gradient_group) and the STATIC partition of each arena into exchange ranges
+        (parallel.ShardedRanges) - the generator's follow its stages, so that a stage's range can leave while backward
+        is still running in the earlier stages; the discriminator's are 256 MiB chunks.  With --shard_optimizer (default
+        under data parallelism; BG_SHARD_OPT=0 switches back to all-reduce + replicated update) every range is
+        reduce-scattered, TF-Adam + EMA run on the owned 1/N and the parameters are all-gathered: Adam moments and EMA
+        shadows then exist only on their owner (``sync_sharded_state`` assembles them for checkpoints and sampling)."""
+        from .parallel import ShardedRanges, new_gradient_group
+        self.pg_grad = None
+        self._param_gathers = {"generator": [], "discriminator": []}
+        self.shards = {}
+        self.shard_opt = False
+        force = os.environ.get("BG_SHARD_OPT", "") == "force"      # (tests: the sharded call sites on a 1-rank RCCL group)
+        if (self.world == 1 and not force) or self.store.device.type != "cuda":
+            return
+        self.pg_grad = new_gradient_group(self.pg)
+        self.shards["generator"] = ShardedRanges(self.g_arena.size, self._g_bucket_starts().values(), self.world, self.rank)
+        self.shards["discriminator"] = ShardedRanges(self.d_arena.size, (), self.world, self.rank)
+        want = os.environ.get("BG_SHARD_OPT", "1") != "0"
+        self.shard_opt = want and (force or all(sh.sharded for sh in self.shards.values()))
 
     def _shard_regularisers(self):
         """The ortho-cosine terms depend on the weights only, so under data parallelism every rank would
@@ -471,6 +494,7 @@ class BigGAN(GANBase):
 
     def _sn_prefetch(self, group, x):
         if x.is_cuda:
+            self._wait_params(group)          # (a sharded update's all-gather of this network may still be in flight)
             for b in getattr(self, "sn_batches", {}).get(group, ()):
                 ops.sn_prefetch(b)
 
@@ -517,12 +541,10 @@ class BigGAN(GANBase):
         st["hi"] = lo
 
     def _g_exchange_range(self, lo, hi):
-        from .parallel import allreduce_flat
         st = self._g_overlap
         self._sn_backward("generator")                      # (only the weights touched since the last call)
         self.store.zero_untouched("generator", lo, hi)
-        works = allreduce_flat(self.g_arena.grads.narrow(0, lo, hi - lo), self.pg, async_op=True)
-        st["ranges"].append((lo, hi, works))
+        st["handles"].extend(self._exchange_begin("generator", lo, hi, st["apply"]))
 
     # ---- data-parallel hooks -----------------------------------------------------------------
     def _reduce_fn(self):
@@ -534,10 +556,69 @@ class BigGAN(GANBase):
             torch.distributed.all_reduce(t, group=pg)
         return red
 
-    def _allreduce_grads(self, arena):
-        if self.world > 1:
-            from .parallel import allreduce_flat
-            allreduce_flat(arena.grads, self.pg)
+    def _exchange_begin(self, group, lo, hi, apply, async_op=True):
+        """Start the exchange of the gradient ranges inside [lo, hi) of an arena on the gradient process group:
+        reduce-scatter when the update that follows is sharded (each rank then holds the summed gradient of the part it
+        owns), all-reduce otherwise (``apply`` False: callers that want the whole summed gradient; or sharding is off).
+        Returns handles for ``_exchange_end``."""
+        from .parallel import reduce_scatter_range
+        arena = self.store.arenas[group]
+        sh = self.shards[group]
+        pg = self.pg_grad if self.pg_grad is not None else self.pg
+        out = []
+        for a, b in sh.containing(lo, hi):
+            if self.shard_opt and apply:
+                w = reduce_scatter_range(arena.grads, a, b, sh, pg, async_op=async_op)
+                out.append((a, b, w, True))
+            else:
+                w = torch.distributed.all_reduce(arena.grads.narrow(0, a, b - a), group=pg, async_op=async_op)
+                out.append((a, b, w, False))
+        return out
+
+    def _exchange_end(self, group, handles, lr, with_ema, apply, grad_scale=1.0):
+        """Wait for each exchanged range in issue order and update it: TF-Adam (+ EMA) on the owned part followed by the
+        asynchronous all-gather of the new parameters (sharded), or on the whole range (replicated).  The all-gathers
+        are waited for by the first reader of that network's parameters (``_wait_params``)."""
+        from .parallel import all_gather_range
+        arena = self.store.arenas[group]
+        sh = self.shards[group]
+        pg = self.pg_grad if self.pg_grad is not None else self.pg
+        for a, b, work, scattered in handles:
+            if work is not None:
+                work.wait()
+            if not apply:
+                continue
+            if scattered:
+                oa, ob = sh.owned(a, b)
+                self._adam(arena, lr, with_ema=with_ema, grad_scale=grad_scale, lo=oa, hi=ob, prepare=False)
+                self._param_gathers[group].append(all_gather_range(arena.params, a, b, sh, pg, async_op=True))
+            else:
+                self._adam(arena, lr, with_ema=with_ema, grad_scale=grad_scale, lo=a, hi=b, prepare=False)
+
+    def _wait_params(self, group=None):
+        """Block the compute stream until the parameters of a network are whole again after a sharded update."""
+        for g in ((group,) if group else tuple(getattr(self, "_param_gathers", {}))):
+            works = self._param_gathers.get(g, ())
+            for w in works:
+                w.wait()
+            if works:
+                del works[:]
+
+    def sync_sharded_state(self):
+        """Assemble the optimiser state that a sharded update keeps only on its owner - Adam m / v and the generator's EMA
+        shadows - on every rank (all-gather per exchange range).  Collective: every rank calls it (checkpoints, sampling
+        with the EMA weights, state comparisons in tests)."""
+        self._wait_params()
+        if not getattr(self, "shard_opt", False):
+            return
+        from .parallel import all_gather_range
+        for group, sh in self.shards.items():
+            arena = self.store.arenas[group]
+            for buf in (arena.m, arena.v, arena.ema):
+                if buf is None:
+                    continue
+                for a, b in sh.ranges:
+                    all_gather_range(buf, a, b, sh, self.pg_grad)
 
     def _adam_prepare(self, arena, lr):
         """Host part of an optimiser step: advance the step count and put the bias-corrected step size
@@ -715,28 +796,28 @@ class BigGAN(GANBase):
             self._sn_backward("discriminator")
             outs.append(out)
         self.store.zero_untouched("discriminator")
-        if defer and self.world > 1:
-            # data parallel: start the all-reduce of the D gradients and return; the generator forward of the
-            # G step does not read D, so it runs while the collective is in flight and _finish_d() (wait +
-            # Adam) is called just before the G step's first use of the discriminator
-            from .parallel import allreduce_flat
-            self._pending_d = (allreduce_flat(self.d_arena.grads, self.pg, async_op=True), bool(apply), 1.0 / vb)
-        else:
-            self._allreduce_grads(self.d_arena)
-            if apply:
-                self._adam(self.d_arena, self.d_learning_rate, with_ema=False, grad_scale=1.0 / vb)
+        if self.shards:
+            # data parallel: start the exchange of the D gradients (reduce-scatter, or all-reduce when the update is
+            # replicated); with ``defer`` return at once - the generator forward of the G step does not read D, so it
+            # runs while the collectives are in flight, and _finish_d() (wait, Adam on the owned part, all-gather of
+            # the parameters) is called just before the G step's first use of the discriminator
+            handles = self._exchange_begin("discriminator", 0, self.d_arena.size, apply)
+            self._pending_d = (handles, bool(apply), 1.0 / vb)
+            if not defer:
+                self._finish_d()
+        elif apply:
+            self._adam(self.d_arena, self.d_learning_rate, with_ema=False, grad_scale=1.0 / vb)
         return self._mean_losses(outs, ("d_loss", "d_cls_loss", "gp"))
 
     def _finish_d(self):
         pending = getattr(self, "_pending_d", None)
         if pending is None:
             return
-        works, apply, gscale = pending
+        handles, apply, gscale = pending
         self._pending_d = None
-        for w in works:
-            w.wait()
         if apply:
-            self._adam(self.d_arena, self.d_learning_rate, with_ema=False, grad_scale=gscale)
+            self._adam_prepare(self.d_arena, self.d_learning_rate)
+        self._exchange_end("discriminator", handles, self.d_learning_rate, False, apply, gscale)
 
     def _mean_losses(self, outs, keys):
         out = outs[-1]
@@ -796,8 +877,9 @@ class BigGAN(GANBase):
         self._set_requires_grad(self.d_vars, False)        # g_loss is minimised over g_vars only
         outs = []
         # data parallel: exchange the generator gradients stage by stage while backward is still running
-        overlap = self.world > 1 and vb == 1 and self.device.type == "cuda" and not getattr(self, "_capturing", False)
-        self._g_overlap = {"hi": self.g_arena.size, "ranges": []} if overlap else None
+        overlap = (vb == 1 and self.device.type == "cuda" and bool(getattr(self, "shards", None))
+                   and not getattr(self, "_capturing", False))
+        self._g_overlap = {"hi": self.g_arena.size, "handles": [], "apply": bool(apply)} if overlap else None
         try:
             self.store.begin_backward("generator")
             for k in range(vb):
@@ -828,16 +910,16 @@ class BigGAN(GANBase):
             self._g_overlap = None
             if apply:
                 self._adam_prepare(self.g_arena, self.g_learning_rate)
-            for lo, hi, works in st["ranges"]:              # in completion order: the last exchange overlaps the
-                for w in works:                             # optimiser of the earlier ranges
-                    w.wait()
-                if apply:
-                    self._adam(self.g_arena, self.g_learning_rate, with_ema=True, grad_scale=1.0, lo=lo, hi=hi,
-                               prepare=False)
+            # in completion order: the last exchange overlaps the optimiser (and the all-gathers) of the earlier ranges
+            self._exchange_end("generator", st["handles"], self.g_learning_rate, True, apply, 1.0)
             return self._mean_losses(outs, ("g_adv", "g_reg", "g_loss", "g_cls_loss"))
         self.store.zero_untouched("generator")
-        self._allreduce_grads(self.g_arena)
-        if apply:
+        if self.shards:
+            handles = self._exchange_begin("generator", 0, self.g_arena.size, apply)
+            if apply:
+                self._adam_prepare(self.g_arena, self.g_learning_rate)
+            self._exchange_end("generator", handles, self.g_learning_rate, True, apply, 1.0 / vb)
+        elif apply:
             self._adam(self.g_arena, self.g_learning_rate, with_ema=True, grad_scale=1.0 / vb)
         return self._mean_losses(outs, ("g_adv", "g_reg", "g_loss", "g_cls_loss"))
 
@@ -1031,11 +1113,10 @@ class BigGAN(GANBase):
                     print_str += ", " + name + ": %.4f" % val
                 if self.rank == 0:
                     print(print_str, flush=True)
-                if (idx + 1) % self.save_freq == 0 and self.rank == 0:                # BigGAN.py:1121-1122
+                if (idx + 1) % self.save_freq == 0:                                   # BigGAN.py:1121-1122
                     self.save(self.checkpoint_dir, self.counter)
             start_batch_id = 0                                                         # BigGAN.py:1164-1166
-            if self.rank == 0:
-                self.save(self.checkpoint_dir, self.counter)
+            self.save(self.checkpoint_dir, self.counter)
 
     # ---- sampling with the EMA weights (BigGAN.py:963-971) ------------------------------------
     def sample(self, z=None, cls_z=None, B=None, use_ema=True):
@@ -1044,6 +1125,7 @@ class BigGAN(GANBase):
         statistics) from the live variables; batch norm uses the population statistics; the spectral-norm
         power iteration still advances ``u`` (its assign is a control dependency of w / sigma, ops.py:743)."""
         B = B or (z.shape[0] if z is not None else self.batch_size)
+        self.sync_sharded_state()             # (data parallel with a sharded update: collective, every rank samples)
         if z is None:
             z = self.sample_z(B)
         if self.acgan and cls_z is None:
@@ -1105,8 +1187,12 @@ class BigGAN(GANBase):
         return out
 
     def save(self, checkpoint_dir, step):
-        """``<checkpoint_dir>/<model_dir>/BigGAN.model-<step>.safetensors`` + a TF-style ``checkpoint`` index."""
+        """``<checkpoint_dir>/<model_dir>/BigGAN.model-<step>.safetensors`` + a TF-style ``checkpoint`` index.
+        Under data parallelism every rank calls it (the sharded optimiser state is gathered first); rank 0 writes."""
         from safetensors.torch import save_file
+        self.sync_sharded_state()
+        if self.rank != 0:
+            return None
         d = self._ckpt_dir(checkpoint_dir)
         os.makedirs(d, exist_ok=True)
         tensors = {k: v.detach().to("cpu").contiguous().clone() for k, v in self.state_tensors().items()}

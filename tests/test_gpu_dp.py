@@ -41,8 +41,9 @@ def _extra(batch, tr, cu, dev_draws, lo, hi):
     return dkw, gkw
 
 
-def _worker(rank, world, port, q, gan_type="hinge"):
+def _worker(rank, world, port, q, gan_type="hinge", shard="1"):
     import sys
+    os.environ["BG_SHARD_OPT"] = shard
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
         sys.path.insert(0, root)
@@ -83,8 +84,14 @@ def _worker(rank, world, port, q, gan_type="hinge"):
     gan.g_step(hi - lo, cu(batch["z_g"][lo:hi]), dev_draws(_slice_draws(batch["aug_fake_g"], lo, hi)),
                after_generator=gan._finish_d, **gkw)
     assert gan._pending_d is None
+    assert gan.shard_opt == (shard != "0") and gan.pg_grad is not None
+    gan.sync_sharded_state()            # collective: parameters whole again, Adam moments / EMA gathered from their owners
     out["d_params"] = t2n(gan.d_arena.params).copy()
     out["g_params"] = t2n(gan.g_arena.params).copy()
+    out["g_ema"] = t2n(gan.g_arena.ema).copy()
+    out["g_v"] = t2n(gan.g_arena.v).copy()
+    out["d_v"] = t2n(gan.d_arena.v).copy()
+    out["n_ranges"] = (len(gan.shards["generator"].ranges), len(gan.shards["discriminator"].ranges))
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -114,6 +121,9 @@ def _single(gan_type="hinge"):
     gan.g_step(B, cu(batch["z_g"]), dev_draws(batch["aug_fake_g"]), **gkw)
     out["d_params"] = t2n(gan.d_arena.params).copy()
     out["g_params"] = t2n(gan.g_arena.params).copy()
+    out["g_ema"] = t2n(gan.g_arena.ema).copy()
+    out["g_v"] = t2n(gan.g_arena.v).copy()
+    out["d_v"] = t2n(gan.d_arena.v).copy()
     return out
 
 
@@ -121,17 +131,19 @@ def _rel(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
 
 
-@pytest.mark.parametrize("gan_type", ["hinge", "ra-dragan"])
-def test_two_rank_data_parallel_matches_single_process(gan_type):
+@pytest.mark.parametrize("gan_type,shard", [("hinge", "1"), ("hinge", "0"), ("ra-dragan", "1")])
+def test_two_rank_data_parallel_matches_single_process(gan_type, shard):
     """hinge: the BASELINE path.  ra-dragan (the reference's default --gan_type): relativistic batch means, the
     global moments of the real batch behind the DRAGAN perturbation and the gradient penalty's global mean all cross
-    the rank boundary."""
+    the rank boundary.  shard "1" (default): reduce-scatter -> TF-Adam + EMA on the owned half of every exchange range
+    -> all-gather of the parameters (last row); "0": all-reduce and a replicated update.  Both must give the
+    single-process parameters, Adam second moments and EMA shadows."""
     ref = _single(gan_type)
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, gan_type)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, gan_type, shard)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(world))
@@ -150,10 +162,14 @@ def test_two_rank_data_parallel_matches_single_process(gan_type):
     # full iteration with the deferred D update: replicas stay identical and follow the single-process weights.
     # (TF-Adam with beta1 = 0 moves every element by ~lr * sign(g): compare the UPDATE, not the weights, and
     # allow the sign noise of near-zero gradient elements)
-    for name in ("d_params", "g_params"):
+    for name in ("d_params", "g_params", "g_ema"):
         assert np.array_equal(res[0][name], res[1][name]), name
         same = np.mean(np.abs(res[0][name].astype(np.float64) - ref[name]) < 1e-7)
         assert same > 0.995, (name, same)
+    for name in ("g_v", "d_v"):          # Adam's second moment = 0.1 g^2 after one step: smooth in the gradient
+        assert np.array_equal(res[0][name], res[1][name]), name
+        assert _rel(res[0][name], ref[name]) < 1e-3, (name, _rel(res[0][name], ref[name]))
+    assert res[0]["n_ranges"][0] >= 5 and res[0]["n_ranges"] == res[1]["n_ranges"]     # generator: one range per stage
 
 
 def _rccl_worker(port, q):
@@ -171,15 +187,37 @@ def _rccl_worker(port, q):
     for gt in ("hinge", "ra-dragan"):
         args = M.parse_args(["--gan_type", gt, "--img_size", "64", "--ch", "8", "--z_dim", "64", "--batch_size", "4"],
                             make_dirs=False)
+        os.environ["BG_SHARD_OPT"] = "0"
         gan = model.BigGAN(args, device="cuda", store=S.VariableStore("cuda", seed=1), process_group=dist.group.WORLD)
         gan.build_model()
         gan.world = 2                           # every `world > 1` branch runs; the collectives go through RCCL
         gan.reg_owner = gan._shard_regularisers()
+        gan._setup_exchange()                   # all-reduce form of the gradient exchange (the group has one rank)
+        assert gan.shards and not gan.shard_opt
         real = gan.synthetic_batch(4)
         for _ in range(3):
             losses = gan.train_step(real)
         torch.cuda.synchronize()
         out[gt] = {k: float(v.item()) for k, v in losses.items()}
+    # the sharded update's call sites (reduce_scatter_tensor / all_gather_into_tensor in place on arena ranges, the
+    # deferred waits, sync_sharded_state) on the 1-rank RCCL group: must reproduce the plain single-process iterations
+    args = M.parse_args(["--gan_type", "hinge", "--img_size", "64", "--ch", "8", "--z_dim", "64", "--batch_size", "4"],
+                        make_dirs=False)
+    runs = []
+    for mode in ("force", "off"):
+        os.environ["BG_SHARD_OPT"] = "force" if mode == "force" else "0"
+        gan = model.BigGAN(args, device="cuda", store=S.VariableStore("cuda", seed=1),
+                           process_group=dist.group.WORLD if mode == "force" else None, seed=7)
+        gan.build_model()
+        assert gan.shard_opt == (mode == "force")
+        real = gan.synthetic_batch(4)
+        for _ in range(2):
+            gan.train_step(real)
+        gan.sync_sharded_state()
+        torch.cuda.synchronize()
+        runs.append([t.detach().cpu().clone() for t in (gan.g_arena.params, gan.d_arena.params, gan.g_arena.ema,
+                                                        gan.g_arena.v)])
+    out["sharded_equals_plain"] = all(torch.equal(a, b) for a, b in zip(*runs))
     dist.barrier()
     dist.destroy_process_group()
     q.put(out)
@@ -198,6 +236,7 @@ def test_collective_call_sites_under_rccl():
     out = q.get(timeout=300)
     p.join(120)
     assert p.exitcode == 0
+    assert out.pop("sharded_equals_plain")
     for gt, losses in out.items():
         assert losses and all(np.isfinite(v) for v in losses.values()), (gt, losses)
     assert "gp" in out["ra-dragan"]

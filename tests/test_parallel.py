@@ -42,6 +42,28 @@ def _worker(rank, world, port, q):
     parallel.broadcast_flat(p, src=0)
     ok3 = p.tolist() == [0.0] * 5
     lo, hi = parallel.shard_batch(64, rank, world)
+    # sharded update on a flat arena (SURVEY 8e last row): reduce-scatter per exchange range -> update of the owned
+    # half -> all-gather, on a second process group; must equal all-reduce + replicated update
+    pg2 = parallel.new_gradient_group()
+    size = 64 * 37
+    sh = parallel.ShardedRanges(size, [64 * 5, 64 * 20], world, rank, max_elems=64 * 8)
+    gen = torch.Generator().manual_seed(3)
+    p0 = torch.randn(size, generator=gen)
+    g_all = [torch.randn(size, generator=gen) for _ in range(world)]
+    p, g = p0.clone(), g_all[rank].clone()
+    works = [(a, b, parallel.reduce_scatter_range(g, a, b, sh, pg2, async_op=True)) for a, b in sh.ranges]
+    gathers = []
+    for a, b, wk in works:
+        wk.wait()
+        oa, ob = sh.owned(a, b)
+        p[oa:ob] -= 0.5 * g[oa:ob]                                   # (stands for TF-Adam on the owned part)
+        gathers.append(parallel.all_gather_range(p, a, b, sh, pg2, async_op=True))
+    for wk in gathers:
+        wk.wait()
+    ok5 = (pg2 is not None and sh.sharded and sh.ranges[0] == (0, 320) and all(b - a <= 512 for a, b in sh.ranges)
+           and sum(b - a for a, b in sh.ranges) == size and sh.containing(320, 1280) == [r for r in sh.ranges if 320 <= r[0] < 1280]
+           and torch.allclose(p, p0 - 0.5 * sum(g_all), atol=1e-6)
+           and not parallel.ShardedRanges(64 * 4, [], 3, 0).sharded)
     # regulariser sharding: identical owner maps on all ranks, every kernel owned once, loads balanced
     from biggan_tensorflow_amd import main as M, model, scope as S
     g = model.BigGAN(M.parse_args(["--gan_type", "hinge", "--img_size", "128", "--ch", "16"], make_dirs=False),
@@ -59,7 +81,7 @@ def _worker(rank, world, port, q):
     total = torch.tensor([float(per_rank)])
     dist.all_reduce(total)
     ok4 = ok4 and name == "c3" and mode == "strong" and int(total.item()) == bench.GLOBAL_BATCH["c3"] == 256
-    q.put((rank, ok1, ok2, ok3, lo, hi, ok4, sorted(owner.items())))
+    q.put((rank, ok1, ok2, ok3 and ok5, lo, hi, ok4, sorted(owner.items())))
     dist.destroy_process_group()
 
 
