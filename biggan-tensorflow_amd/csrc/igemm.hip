@@ -1034,6 +1034,18 @@ static void conv16_dgrad_params(const BgConvDesc* d, bool padded, NN16Params& p)
 
 static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// Input gradient of a reflect-padded 3 x 3 convolution WITHOUT the padded grid (ops.py:81-82, 94 under autodiff): the
+// plain transposed gather on the H x W map (zero-padding semantics: halo-tile kernel on 16 / 32 / 64 maps, position-major
+// tap kernel on 4 x 4 / 8 x 8) plus two thin launches that add the taps of the mirrored padded rows / columns into
+// rows / columns 1 and H - 2 (NN16Params::ring).  BG_DGRAD_RING=0: the padded grid + reflect_fold_kernel of round 2 (A/B).
+static bool dgrad_ring_ok(const BgConvDesc* d) {
+    const char* e = getenv("BG_DGRAD_RING");
+    if (e && atoi(e) == 0) return false;
+    return d->pad_mode == BG_PAD_REFLECT && d->pad_lo == 1 && d->k == 3 && (d->stride == 1 || d->stride == 2) &&
+           d->H >= 4 && d->W >= 4 && d->H % d->stride == 0 && d->W % d->stride == 0 && d->Ho == d->H / d->stride &&
+           d->Wo == d->W / d->stride;
+}
+
 }  // namespace bg
 
 using namespace bg;
@@ -1083,9 +1095,10 @@ size_t bg_conv2d_dgrad_workspace_bytes(const BgConvDesc* d) {
     if (!d) return 0;
     const int z = d->stride * d->stride;
     if (resident_dgrad(d)) {
-        const bool padded = d->pad_mode == BG_PAD_REFLECT && d->pad_lo > 0;
+        const bool padded = d->pad_mode == BG_PAD_REFLECT && d->pad_lo > 0 && !dgrad_ring_ok(d);
         NN16Params p;
         conv16_dgrad_params(d, padded, p);
+        p.g.reflect = 0;
         const int64_t out_elems = (int64_t)d->N * p.g.Ho * p.g.Wo * d->Cin;
         size_t b = nn16_workspace_bytes(p, GATHER_TCONV, z, out_elems);
         if (padded) b = align256(b) + align256((size_t)out_elems * (d->x_dtype == BG_F32 ? 4 : 2));
@@ -1104,16 +1117,29 @@ int bg_conv2d_dgrad(const BgConvDesc* d, const void* dy, const void* w, const fl
     BG_REQUIRE(d->H % d->stride == 0 && d->W % d->stride == 0, "conv dgrad: H,W must be multiples of stride");
     Tag tag("conv2d_dgrad", d);
     if (resident_dgrad(d)) {
-        const bool padded = d->pad_mode == BG_PAD_REFLECT && d->pad_lo > 0;
+        const bool ring = d->pad_mode == BG_PAD_REFLECT && d->pad_lo > 0 && dgrad_ring_ok(d);
+        const bool padded = d->pad_mode == BG_PAD_REFLECT && d->pad_lo > 0 && !ring;
         NN16Params r;
         conv16_dgrad_params(d, padded, r);
+        r.g.reflect = 0;                        // (the mirrored taps are the ring launches' / the fold's business)
         r.A = dy; r.B = w; r.alpha = alpha_dev;
         r.out_f32 = d->x_dtype == BG_F32;
         const int64_t out_elems = (int64_t)d->N * r.g.Ho * r.g.Wo * d->Cin;
         ProfScope prof(as_stream(stream), conv_flops(d, false), tag.s, tag.bytes);
         if (!padded) {
             r.out = dx; r.accumulate = accumulate;
-            return launch_nn16(r, GATHER_TCONV, d->stride * d->stride, out_elems, ws, ws_bytes, as_stream(stream));
+            const NN16Params plain = r;
+            rc = launch_nn16(r, GATHER_TCONV, d->stride * d->stride, out_elems, ws, ws_bytes, as_stream(stream));
+            if (rc || !ring) return rc;
+            for (int which = 1; which <= 2; ++which) {
+                NN16Params q = plain;
+                q.ring = which;
+                q.ring_lines = d->stride == 1 ? 2 : 1;
+                q.accumulate = 1;
+                rc = launch_nn16_ring(q, as_stream(stream));
+                if (rc) return rc;
+            }
+            return BG_OK;
         }
         // gradient on the reflect-padded grid, then every padded position is added to the pixel it mirrors
         const size_t pbytes = align256((size_t)out_elems * (r.out_f32 ? 4 : 2));

@@ -87,13 +87,14 @@ __device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast
 // ------------------------------------------------------------------------------------------
 constexpr int NN16_BM = 128;      // block tile rows; the K step is 64 bf16 = one 128-byte LDS row
 constexpr int NN16_TAPS = 4;      // taps per axis one block walks (kernel sizes 1, 3, 4)
-constexpr int NN16_TAB = 2 * NN16_TAPS * NN16_BM * 4;          // gather tables [axis][tap][row] of int32 behind the stages
-constexpr int nn16_lds_bytes(int TN) {
+constexpr int NN16_RING_TAPS = 8; // per-axis tap slots of a ring launch (NN16Params::ring): k real + k mirrored, k <= 4
+constexpr int nn16_lds_bytes(int TN, int TAPS = NN16_TAPS) {
     const int stage = (NN16_BM + 32 * TN) * 128;
     const int epi = NN16_BM * (32 * TN + 4) * 4;
+    const int tab = 2 * TAPS * NN16_BM * 4;                    // gather tables [axis][tap][row] of int32 behind the stages
     // + output pixel of every row + the tile's tap flags (in the dynamic block on purpose: a static __shared__ variable
     // moves the stages off their 1 KB alignment, which costs the LDS-DMA writes of the HBM-bound layers ~25 %)
-    return (2 * stage + NN16_TAB > epi ? 2 * stage + NN16_TAB : epi) + NN16_BM * 4 + 16;
+    return (2 * stage + tab > epi ? 2 * stage + tab : epi) + NN16_BM * 4 + 16;
 }
 constexpr int NN16_NOSRC = -(1 << 30);                         // table entry of a tap without a source pixel
 
@@ -115,13 +116,28 @@ __device__ __forceinline__ int64_t nn16_src_off(const Gather& g, const RowPos& r
 
 // row of the implicit GEMM -> output pixel of this stride phase (shifts when the phase grid is a power of two: the
 // divisions of decompose_row cost ~90 VALU instructions per row, as much as several K steps of a C = 96 layer)
-template <int MODE, bool PM>
+// padded position that tf.pad(REFLECT) (pad 1) fills from pixel o of an axis of n pixels, beyond o itself: -1 for o = 1,
+// n for o = n - 2 (when the high border is padded at all); NN16_NOMIRROR otherwise
+constexpr int NN16_NOMIRROR = -(1 << 20);
+__device__ __forceinline__ int nn16_mirror_pos(int o, int n, bool hi) {
+    return o == 1 ? -1 : ((hi && o == n - 2) ? n : NN16_NOMIRROR);
+}
+
+template <int MODE, bool PM, bool RING = false>
 __device__ __forceinline__ RowPos nn16_row(const NN16Params& p, int m, int ph, int pw) {
     RowPos r;
     if (PM) {                                      // image fastest: every row of a tile sits at (nearly) the same position
         r.valid = m < p.M;
         const int pos = m / p.g.Nb;
         r.b = m - pos * p.g.Nb;
+        if (RING) {                                // the rows (ring 1) / columns (ring 2) that receive mirrored taps
+            const int len = p.ring == 1 ? p.g.Wo : p.g.Ho, other = p.ring == 1 ? p.g.Ho : p.g.Wo;
+            const int line = pos / len, idx = pos - line * len;
+            const int sel = line == 0 ? 1 : other - 2;
+            r.ho = p.ring == 1 ? sel : idx;
+            r.wo = p.ring == 1 ? idx : sel;
+            return r;
+        }
         const int hq = pos / p.g.Wq;
         r.ho = hq * p.g.pstep + ph;
         r.wo = (pos - hq * p.g.Wq) * p.g.pstep + pw;
@@ -140,8 +156,14 @@ __device__ __forceinline__ RowPos nn16_row(const NN16Params& p, int m, int ph, i
 
 // PM: position-major rows and a K walk over the tile's own taps (NN16Params::posmajor); the image-major form is its own
 // instantiation because the tap bookkeeping costs the short-K launches (1 x 1 convolutions: 3 K steps) 25 %.
-template <int TN, int MODE, bool PM>
+// RING (NN16Params::ring; PM launches of transposed gathers only): 8 tap slots per axis = real taps followed by the taps
+// of the mirrored padded position.
+template <int TN, int MODE, bool PM, bool RING = false>
 __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
+    static_assert(!RING || (PM && MODE == GATHER_TCONV), "ring launches are position-major transposed gathers");
+    constexpr int TAPS = RING ? NN16_RING_TAPS : NN16_TAPS;
+    constexpr int LDS_BYTES = nn16_lds_bytes(TN, TAPS);
+    typedef typename std::conditional<RING, uint64_t, unsigned>::type mask_t;
     constexpr int BM = NN16_BM, BN = 32 * TN;
     constexpr int JA = BM / 32, JB = BN / 32;      // LDS-DMA instructions per wave and K step
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
@@ -177,6 +199,14 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
         nkh = (g.k - kh0 + g.stride - 1) / g.stride;
         nkw = (g.k - kw0 + g.stride - 1) / g.stride;
     }
+    // ring launches: per axis n_real real taps (kk = i) followed by g.k taps of the mirrored position (kk = i - n_real)
+    int nrh = 0, nrw = 0;
+    if (RING) {
+        nrh = p.ring == 1 ? 0 : g.k;
+        nrw = p.ring == 1 ? g.k : 0;
+        nkh = nrh + (p.ring == 1 ? g.k : 0);
+        nkw = nrw + g.k;
+    }
     const int C8 = p.C >> 3;
     const int ntap = nkh * nkw;
 
@@ -188,26 +218,34 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
     // s_any: bit (axis * NN16_TAPS + i) = some row of this tile has a source under tap i of that axis.  Taps without
     // any are left out of the K walk: the border tiles of a position-major launch (p.posmajor) then cost what their
     // sources cost, not k x k zero-page tiles.
-    unsigned& s_any = *reinterpret_cast<unsigned*>(smem + nn16_lds_bytes(TN) - 16);
+    unsigned& s_any = *reinterpret_cast<unsigned*>(smem + LDS_BYTES - 16);
     if (PM) {
         if (t == 0) s_any = 0;
         __syncthreads();
     }
     unsigned any_local = 0;
     int* tabh = reinterpret_cast<int*>(smem + 2 * STAGE);
-    int* tabw = tabh + NN16_TAPS * BM;
-    for (int e = t; e < 2 * NN16_TAPS * BM; e += 256) {
-        const int axis = e / (NN16_TAPS * BM), i = (e / BM) % NN16_TAPS, row = e % BM;
-        const RowPos r = nn16_row<MODE, PM>(p, m0 + row, ph, pw);
+    int* tabw = tabh + TAPS * BM;
+    for (int e = t; e < 2 * TAPS * BM; e += 256) {
+        const int axis = e / (TAPS * BM), i = (e / BM) % TAPS, row = e % BM;
+        const RowPos r = nn16_row<MODE, PM, RING>(p, m0 + row, ph, pw);
         int v = NN16_NOSRC;
         if (r.valid && i < (axis ? nkw : nkh)) {
-            const int kk = (axis ? kw0 : kh0) + i * kstep;
-            const int o = axis ? r.wo : r.ho, n = axis ? g.Ws : g.Hs;
+            int kk = (axis ? kw0 : kh0) + i * kstep;
+            int o = axis ? r.wo : r.ho;
+            const int n = axis ? g.Ws : g.Hs;
+            if (RING) {
+                const int nr = axis ? nrw : nrh;
+                if (i >= nr) {                         // tap of the mirrored padded position
+                    kk = i - nr;
+                    o = nn16_mirror_pos(o, axis ? g.Wo : g.Ho, p.ring_lines == 2);
+                }
+            }
             const int src = MODE == GATHER_CONV ? conv_src(o, kk, g.stride, g.pad, g.reflect, n)
-                                                : tconv_src_from_num(o + g.pad - kk, g.stride, n);
+                                                : (o == NN16_NOMIRROR ? -1 : tconv_src_from_num(o + g.pad - kk, g.stride, n));
             if (src >= 0) {
                 v = axis ? src : (r.b * g.Hs + src) * g.Ws;
-                any_local |= 1u << (axis * NN16_TAPS + i);
+                any_local |= 1u << (axis * TAPS + i);
             }
         }
         tabh[e] = v;
@@ -215,10 +253,10 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
     if (PM && any_local) atomicOr(&s_any, any_local);
     // output pixel of every row (transposed gathers: rows enumerate a stride phase, possibly of a padded grid), behind
     // everything the epilogue overlays; 0xffffffff = no output
-    unsigned* tabo = reinterpret_cast<unsigned*>(smem + nn16_lds_bytes(TN) - 16 - BM * 4);
+    unsigned* tabo = reinterpret_cast<unsigned*>(smem + LDS_BYTES - 16 - BM * 4);
     constexpr bool use_tabo = MODE == GATHER_TCONV || PM;
     if (use_tabo && t < BM) {
-        const RowPos r = nn16_row<MODE, PM>(p, m0 + t, ph, pw);
+        const RowPos r = nn16_row<MODE, PM, RING>(p, m0 + t, ph, pw);
         tabo[t] = (r.valid && r.ho < g.Ho && r.wo < g.Wo) ? (unsigned)((r.b * g.Ho + r.ho) * g.Wo + r.wo) : 0xffffffffu;
     }
 
@@ -234,21 +272,21 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
 
     __syncthreads();                     // tables (and s_any) complete
     // PM: taps this tile walks, bit (ih * NN16_TAPS + iw), in the (ih, iw) order of the packed weights
-    unsigned tapmask = 0;
+    mask_t tapmask = 0;
     if (PM) {
         const unsigned any = __builtin_amdgcn_readfirstlane(s_any);      // block-uniform: the K loop stays scalar
         for (int i = 0; i < nkh; ++i)
             for (int j = 0; j < nkw; ++j)
-                if (((any >> i) & (any >> (NN16_TAPS + j)) & 1u) != 0) tapmask |= 1u << (i * NN16_TAPS + j);
+                if (((any >> i) & (any >> (TAPS + j)) & 1u) != 0) tapmask |= (mask_t)1 << (i * TAPS + j);
     }
-    const int nsteps_all = ((PM ? __builtin_popcount(tapmask) : ntap) * C8 + 7) >> 3;
+    const int nsteps_all = ((PM ? __builtin_popcountll((uint64_t)tapmask) : ntap) * C8 + 7) >> 3;
     const int sps = (nsteps_all + p.splitk - 1) / p.splitk;
     const int it0 = zs * sps;
     const int nsteps = max(0, min(nsteps_all, it0 + sps) - it0);
 
     // K cursor of this lane.  Image-major: tap index tidx = (ih, iw).  PM: rem = the taps from the current one on
     // (lowest set bit = current).
-    unsigned rem = tapmask;
+    mask_t rem = tapmask;
     int tidx = 0, c8, ih = 0, iw = 0;
     {
         const int kk = it0 * 8 + cch;
@@ -267,20 +305,21 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
         bool kvalid;
         if (PM) {
             kvalid = rem != 0;
-            const int bit = kvalid ? __builtin_ctz(rem) : 0;
-            ih = bit / NN16_TAPS;
-            iw = bit % NN16_TAPS;
+            const int bit = kvalid ? __builtin_ctzll((uint64_t)rem) : 0;
+            ih = bit / TAPS;
+            iw = bit % TAPS;
         } else {
             kvalid = tidx < ntap;
         }
-        const int* th = tabh + (ih & (NN16_TAPS - 1)) * BM + rsub;
-        const int* tw = tabw + (iw & (NN16_TAPS - 1)) * BM + rsub;
+        const int* th = tabh + (ih & (TAPS - 1)) * BM + rsub;
+        const int* tw = tabw + (iw & (TAPS - 1)) * BM + rsub;
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
             const int pix = th[32 * j] + tw[32 * j];
             asrc[j] = (kvalid & (pix >= 0)) ? abase + (uint64_t)(unsigned)pix * ald2 : zero;
         }
-        const int kh = kh0 + ih * kstep, kw = kw0 + iw * kstep;
+        const int kh = RING ? (ih >= nrh ? ih - nrh : ih) : kh0 + ih * kstep;
+        const int kw = RING ? (iw >= nrw ? iw - nrw : iw) : kw0 + iw * kstep;
         const unsigned char* wt = bbase + 2 * (int64_t)(kh * g.k + kw) * p.tap_stride;
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
@@ -1268,6 +1307,50 @@ static NN16Plan plan_nn16(const NN16Params& p, int mode, int zdim, bool allow_sp
 size_t nn16_workspace_bytes(const NN16Params& p, int mode, int zdim, int64_t out_elems) {
     const NN16Plan pl = plan_nn16(p, mode, zdim, true);
     return pl.splitk > 1 ? (size_t)pl.splitk * out_elems * sizeof(float) : 0;
+}
+
+// ring launches (NN16Params::ring): mirrored taps of the gradient of tf.pad(REFLECT), accumulated into dx
+template <int TN>
+static int launch_nn16_ring_inst(const NN16Params& p, dim3 grid, hipStream_t s) {
+    constexpr int lds = nn16_lds_bytes(TN, NN16_RING_TAPS);
+    if (!lds_opt_in(reinterpret_cast<const void*>(&nn16_kernel<TN, GATHER_TCONV, true, true>), lds)) return BG_ERR_LAUNCH;
+    hipLaunchKernelGGL((nn16_kernel<TN, GATHER_TCONV, true, true>), grid, dim3(256), lds, s, p);
+    return BG_OK;
+}
+
+int launch_nn16_ring(NN16Params& p, hipStream_t s) {
+    BG_REQUIRE(p.ring == 1 || p.ring == 2, "nn16 ring launch: ring must be 1 or 2");
+    BG_REQUIRE(p.g.k >= 1 && p.g.k <= NN16_RING_TAPS / 2 && p.g.Ho >= 4 && p.g.Wo >= 4 && p.accumulate == 1,
+               "nn16 ring launch: kernel size %d / map %d x %d not supported", p.g.k, p.g.Ho, p.g.Wo);
+    BG_REQUIRE(p.C % 8 == 0 && p.N % 8 == 0 && p.g.ld % 8 == 0 && p.out_ld % 8 == 0, "nn16 ring launch: channels %% 8");
+    const int len = p.ring == 1 ? p.g.Wo : p.g.Ho;
+    p.g.pstep = 1;
+    p.g.Hq = p.ring_lines;
+    p.g.Wq = len;
+    p.M = p.g.Nb * p.ring_lines * len;
+    p.posmajor = 1;
+    p.splitk = 1;                       // (slabs live in output coordinates: a ring launch touches a few lines of them)
+    p.slabs = nullptr;
+    p.zfold = 0;
+    p.pow2 = 0;
+    int tn = 4, best = 1 << 30;
+    for (int c = 4; c >= 1; --c) {      // least padded output channels; ties: the wider tile
+        const int padded = (p.N + 32 * c - 1) / (32 * c) * (32 * c);
+        if (padded < best) { best = padded; tn = c; }
+    }
+    p.tiles_m = (p.M + NN16_BM - 1) / NN16_BM;
+    p.tiles_n = (p.N + 32 * tn - 1) / (32 * tn);
+    dim3 grid(p.tiles_m * p.tiles_n, 1, 1);
+    int rc;
+    switch (tn) {
+        case 1: rc = launch_nn16_ring_inst<1>(p, grid, s); break;
+        case 2: rc = launch_nn16_ring_inst<2>(p, grid, s); break;
+        case 3: rc = launch_nn16_ring_inst<3>(p, grid, s); break;
+        default: rc = launch_nn16_ring_inst<4>(p, grid, s); break;
+    }
+    if (rc) return rc;
+    BG_LAUNCH_CHECK();
+    return BG_OK;
 }
 
 template <int TN, int MODE, bool PM>

@@ -384,6 +384,49 @@ def test_position_major_rows_match_the_image_major_walk(kind, N, H, Cin, Cout, k
         Fn.set_precision("fp32")
 
 
+@pytest.mark.parametrize("N,H,Cin,Cout,s,xdt", [(3, 4, 16, 24, 1, torch.bfloat16), (130, 4, 8, 16, 1, torch.bfloat16),
+                                                 (2, 8, 24, 16, 1, torch.bfloat16), (2, 16, 32, 16, 1, torch.bfloat16),
+                                                 (1, 32, 32, 8, 1, torch.bfloat16), (70, 8, 16, 16, 2, torch.bfloat16),
+                                                 (2, 16, 16, 24, 2, torch.bfloat16), (1, 64, 8, 8, 2, torch.bfloat16),
+                                                 (2, 16, 3, 16, 2, torch.float32), (2, 12, 3, 8, 1, torch.float32),
+                                                 (2, 6, 8, 8, 1, torch.bfloat16), (1, 10, 8, 16, 2, torch.bfloat16)])
+def test_reflect_conv_input_gradient_without_the_padded_grid(N, H, Cin, Cout, s, xdt):
+    """Input gradient of tf.pad(REFLECT) + VALID conv (ops.py:81-82, 94): the plain transposed gather on the H x W map
+    plus the two mirrored-tap launches (igemm16.hip NN16Params::ring) against the float64 gradient, EXACTLY - the operands
+    are small integers, so every product and sum is exact in bf16 / fp32 and any missing, doubled or misplaced mirrored
+    tap shows - and against round 2's padded-grid + fold form (BG_DGRAD_RING=0).  4 x 4 ... 64 x 64 maps, both strides,
+    non-power-of-two maps, batches that put one, two or many positions into a 128-row tile, the fp32 image gradient of
+    the discriminator's first layer."""
+    from biggan_tensorflow_amd import functional as Fn, hip
+    Fn.set_precision("bf16")
+    try:
+        rng = np.random.default_rng(N * 131 + H * 7 + Cin + Cout + s)
+        x = rng.integers(-2, 3, size=(N, H, H, Cin)).astype(np.float64)
+        w = rng.integers(-1, 2, size=(3, 3, Cin, Cout)).astype(np.float64)
+        Ho = H // s
+        g = (rng.integers(-1, 2, size=(N, Ho, Ho, Cout)) * (rng.random((N, Ho, Ho, Cout)) < 0.25)).astype(np.float64)
+        xt = torch.tensor(x, requires_grad=True)
+        xin = F.pad(xt.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect")
+        yr = F.conv2d(xin.contiguous(), torch.tensor(w).permute(3, 2, 0, 1).contiguous(), stride=s).permute(0, 2, 3, 1)
+        assert tuple(yr.shape) == g.shape
+        yr.backward(torch.tensor(g))
+        ref = xt.grad.numpy()
+        assert np.abs(ref).max() <= 256               # exactly representable in bf16
+        got = {}
+        for ring in ("1", "0"):
+            os.environ["BG_DGRAD_RING"] = ring
+            xc, wc = cu(x, True, xdt), cu(w, True)
+            y = Fn.Conv2dFn.apply(xc, wc, None, s, 1, Ho, Ho, hip.PAD_REFLECT)
+            y.backward(cu(g, dtype=y.dtype))
+            got[ring] = f64(xc.grad)
+        assert np.array_equal(got["0"], ref), ("padded-grid form", np.abs(got["0"] - ref).max())
+        bad = np.argwhere(got["1"] != ref)
+        assert bad.size == 0, ("ring form", bad[:8].tolist(), np.abs(got["1"] - ref).max())
+    finally:
+        os.environ.pop("BG_DGRAD_RING", None)
+        Fn.set_precision("fp32")
+
+
 @pytest.mark.parametrize("rows,cols,ld", [(9 * 64, 64, 64), (16 * 96, 192, 192), (4608, 384, 384), (200, 24, 120)])
 def test_gram16_from_packed_weights(rows, cols, ld):
     """bg_gram16: W^T W of a bf16 row-major matrix (the regulariser's Gram from the packed copy of w / sigma, also as a

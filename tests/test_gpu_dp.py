@@ -201,6 +201,8 @@ def _rccl_worker(port, q):
         out[gt] = {k: float(v.item()) for k, v in losses.items()}
     # the sharded update's call sites (reduce_scatter_tensor / all_gather_into_tensor in place on arena ranges, the
     # deferred waits, sync_sharded_state) on the 1-rank RCCL group: must reproduce the plain single-process iterations
+    # (up to the run-to-run noise of atomically accumulated reductions, which TF-Adam with beta1 = 0 turns into +-lr on
+    # elements whose gradient is ~0: compare like the 2-rank test does)
     args = M.parse_args(["--gan_type", "hinge", "--img_size", "64", "--ch", "8", "--z_dim", "64", "--batch_size", "4"],
                         make_dirs=False)
     runs = []
@@ -217,7 +219,9 @@ def _rccl_worker(port, q):
         torch.cuda.synchronize()
         runs.append([t.detach().cpu().clone() for t in (gan.g_arena.params, gan.d_arena.params, gan.g_arena.ema,
                                                         gan.g_arena.v)])
-    out["sharded_equals_plain"] = all(torch.equal(a, b) for a, b in zip(*runs))
+    same = [float(((a - b).abs() < 1e-7).double().mean()) for a, b in zip(runs[0][:3], runs[1][:3])]
+    relv = float((runs[0][3] - runs[1][3]).norm() / runs[1][3].norm())
+    out["sharded_equals_plain"] = (min(same) > 0.995 and relv < 1e-3, same, relv)
     dist.barrier()
     dist.destroy_process_group()
     q.put(out)
@@ -236,7 +240,8 @@ def test_collective_call_sites_under_rccl():
     out = q.get(timeout=300)
     p.join(120)
     assert p.exitcode == 0
-    assert out.pop("sharded_equals_plain")
+    eq = out.pop("sharded_equals_plain")
+    assert eq[0], eq
     for gt, losses in out.items():
         assert losses and all(np.isfinite(v) for v in losses.values()), (gt, losses)
     assert "gp" in out["ra-dragan"]

@@ -544,9 +544,10 @@ def test_pmc_summary_classifies_the_kernel_names_of_this_build():
 
 def test_workspace_queries_run_the_bf16_planner_on_the_host():
     """The workspace queries of the bf16-resident convolutions are pure host code and run the same tile / split-K planner
-    as the launch (igemm16.hip plan_nn16, incl. the position-major decision for small maps): with either setting of
-    BG_NN16_POSMAJOR the input-gradient workspace holds at least the gradient on the reflect-padded grid, plus whole
-    fp32 split-K slabs of it."""
+    as the launch (igemm16.hip plan_nn16, incl. the position-major decision for small maps).  Default form of the
+    reflect-padded input gradient (plain transposed gather + mirrored-tap launches): whole fp32 split-K slabs of the
+    H x W gradient, nothing else; BG_DGRAD_RING=0 (round 2's form): at least the gradient on the reflect-padded grid,
+    plus whole slabs of it - with either setting of BG_NN16_POSMAJOR."""
     import ctypes
     L = hip.lib()
     try:
@@ -558,10 +559,15 @@ def test_workspace_queries_run_the_bf16_planner_on_the_host():
             padded = N * Hp * Hp * C
             for pm in ("0", "1"):
                 os.environ["BG_NN16_POSMAJOR"] = pm
+                os.environ["BG_DGRAD_RING"] = "0"
                 nb = int(L.bg_conv2d_dgrad_workspace_bytes(ctypes.byref(d)))
                 assert nb >= padded * 2, (N, H, pm, nb)
                 slabs = nb - ((padded * 2 + 255) // 256 * 256)
                 assert slabs % (padded * 4) == 0 and slabs // (padded * 4) <= 16, (N, H, pm, nb)
+                os.environ.pop("BG_DGRAD_RING")
+                nb = int(L.bg_conv2d_dgrad_workspace_bytes(ctypes.byref(d)))
+                assert nb % (N * H * H * C * 4) == 0 and nb // (N * H * H * C * 4) <= 16, (N, H, pm, nb)
                 assert int(L.bg_conv2d_fwd_workspace_bytes(ctypes.byref(d))) % (N * (H // s) ** 2 * Co * 4) == 0
     finally:
         os.environ.pop("BG_NN16_POSMAJOR", None)
+        os.environ.pop("BG_DGRAD_RING", None)
