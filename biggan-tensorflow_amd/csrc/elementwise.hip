@@ -1112,7 +1112,9 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_fwd_bf16x8_kernel(
 __global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_bwd_dx_bf16x8_kernel(
     const __bf16* __restrict__ x, const __bf16* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta, int per_sample,
-    const float* __restrict__ alpha, const float* __restrict__ cm, __bf16* __restrict__ dx, int rows, int HW, int CV) {
+    const float* __restrict__ alpha, const float* __restrict__ cm, __bf16* dx, const __bf16* add, int rows, int HW,
+    int CV) {
+    // add (may alias dx): dx = add + gradient - the sum with the other branch of a forked tensor, fused (ops.py:253/263)
     const int gtid = blockIdx.x * EW_BLOCK + threadIdx.x;
     const int cv = gtid % CV, c = cv * 8, C = CV * 8;
     const int rstep = (gridDim.x * EW_BLOCK) / CV;
@@ -1140,6 +1142,12 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_bwd_dx_bf16x8_kernel(
             const float g = alpha ? dv[j] * prelu_d(pre, al[j]) : dv[j];
             out[j] = rs[j] * (g * ga[j] - m1[j] - xh * m2[j]);
         }
+        if (add) {
+            float av[8];
+            bf16x8_load(add + (int64_t)r * C + c, av);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] += av[j];
+        }
         bf16x8_store(dx + (int64_t)r * C + c, out);
     }
 }
@@ -1147,8 +1155,8 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_bwd_dx_bf16x8_kernel(
 // stand-alone PReLU (ops.py:532) and its input gradient, same scheme
 template <bool BWD>
 __global__ __launch_bounds__(EW_BLOCK) void prelu_bf16x8_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy,
-                                                                 const float* __restrict__ alpha, __bf16* __restrict__ out,
-                                                                 int rows, int CV) {
+                                                                 const float* __restrict__ alpha, __bf16* out,
+                                                                 const __bf16* add, int rows, int CV) {
     const int gtid = blockIdx.x * EW_BLOCK + threadIdx.x;
     const int c = (gtid % CV) * 8, C = CV * 8;
     const int rstep = (gridDim.x * EW_BLOCK) / CV;
@@ -1160,6 +1168,12 @@ __global__ __launch_bounds__(EW_BLOCK) void prelu_bf16x8_kernel(const __bf16* __
         if (BWD) bf16x8_load(dy + (int64_t)r * C + c, dv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = BWD ? dv[j] * prelu_d(xv[j], al[j]) : prelu_f(xv[j], al[j]);
+        if (BWD && add) {
+            float av[8];
+            bf16x8_load(add + (int64_t)r * C + c, av);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += av[j];
+        }
         bf16x8_store(out + (int64_t)r * C + c, o);
     }
 }
@@ -1228,7 +1242,7 @@ template <int VEC, class TX, class TY>
 __global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_bwd_dx_t_kernel(
     const TX* __restrict__ x, const TY* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta, int per_sample,
-    const float* __restrict__ alpha, const float* __restrict__ cm, TX* __restrict__ dx, int N, int HW, int C) {
+    const float* __restrict__ alpha, const float* __restrict__ cm, TX* dx, const TX* add, int N, int HW, int C) {
     const int CV = C / VEC;
     const int64_t total = (int64_t)N * HW * CV;
     for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_BLOCK) {
@@ -1251,6 +1265,12 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_bwd_dx_t_kernel(
             const float g = alpha ? dv[j] * prelu_d(pre, al[j]) : dv[j];
             out[j] = rs[j] * (g * ga[j] - m1[j] - xh * m2[j]);
         }
+        if (add) {
+            float av[VEC];
+            loadv<VEC>(add + i * VEC, av);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) out[j] += av[j];
+        }
         storev<VEC>(dx + i * VEC, out);
     }
 }
@@ -1272,7 +1292,7 @@ __global__ __launch_bounds__(EW_BLOCK) void prelu_fwd_t_kernel(const TX* __restr
 
 template <int VEC, class TX, class TY>
 __global__ __launch_bounds__(EW_BLOCK) void prelu_bwd_dx_t_kernel(const TX* __restrict__ x, const TY* __restrict__ dy,
-                                                                   const float* __restrict__ alpha, TX* __restrict__ dx,
+                                                                   const float* __restrict__ alpha, TX* dx, const TX* add,
                                                                    int64_t total_v, int C) {
     const int CV = C / VEC;
     for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total_v; i += (int64_t)gridDim.x * EW_BLOCK) {
@@ -1283,6 +1303,12 @@ __global__ __launch_bounds__(EW_BLOCK) void prelu_bwd_dx_t_kernel(const TX* __re
         loadv<VEC>(alpha + c, al);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) out[j] = dv[j] * prelu_d(xv[j], al[j]);
+        if (add) {
+            float av[VEC];
+            loadv<VEC>(add + i * VEC, av);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) out[j] += av[j];
+        }
         storev<VEC>(dx + i * VEC, out);
     }
 }
@@ -2562,15 +2588,15 @@ int bg_bn_apply_act_bwd_reduce_t(const void* x, int x_dtype, const void* dy, int
 
 int bg_bn_apply_act_bwd_dx_t(const void* x, int x_dtype, const void* dy, int y_dtype, const float* mean, const float* rstd,
                              const float* gamma, const float* beta, int per_sample, const float* alpha, const float* cm,
-                             void* dx, int N, int HW, int C, void* stream) {
+                             void* dx, const void* dx_add, int N, int HW, int C, void* stream) {
     BG_REQUIRE(x && dy && mean && rstd && gamma && beta && cm && dx && N > 0 && HW > 0 && C > 0 && BG_DT_OK(x_dtype) &&
                    BG_DT_OK(y_dtype), "bg_bn_apply_act_bwd_dx_t: bad argument");
     const int64_t total = (int64_t)N * HW * C;
     if (x_dtype == BG_BF16 && y_dtype == BG_BF16 && C % 8 == 0 && (int64_t)N * HW < (int64_t(1) << 31) &&
-        ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0) {
+        ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)dx_add & 15) == 0) {
         hipLaunchKernelGGL(bn_apply_act_bwd_dx_bf16x8_kernel, dim3(bn_x8_grid((int64_t)N * HW, C / 8)), dim3(EW_BLOCK), 0,
                            as_stream(stream), (const __bf16*)x, (const __bf16*)dy, mean, rstd, gamma, beta, per_sample,
-                           alpha, cm, (__bf16*)dx, N * HW, HW, C / 8);
+                           alpha, cm, (__bf16*)dx, (const __bf16*)dx_add, N * HW, HW, C / 8);
         BG_LAUNCH_CHECK();
         return BG_OK;
     }
@@ -2578,12 +2604,12 @@ int bg_bn_apply_act_bwd_dx_t(const void* x, int x_dtype, const void* dy, int y_d
         BG_DISPATCH_XY(x_dtype, y_dtype,
                        hipLaunchKernelGGL((bn_apply_act_bwd_dx_t_kernel<4, TX, TY>), dim3(ew_grid(total / 4)),
                                           dim3(EW_BLOCK), 0, as_stream(stream), (const TX*)x, (const TY*)dy, mean, rstd,
-                                          gamma, beta, per_sample, alpha, cm, (TX*)dx, N, HW, C));
+                                          gamma, beta, per_sample, alpha, cm, (TX*)dx, (const TX*)dx_add, N, HW, C));
     else
         BG_DISPATCH_XY(x_dtype, y_dtype,
                        hipLaunchKernelGGL((bn_apply_act_bwd_dx_t_kernel<1, TX, TY>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0,
                                           as_stream(stream), (const TX*)x, (const TY*)dy, mean, rstd, gamma, beta,
-                                          per_sample, alpha, cm, (TX*)dx, N, HW, C));
+                                          per_sample, alpha, cm, (TX*)dx, (const TX*)dx_add, N, HW, C));
     BG_LAUNCH_CHECK();
     return BG_OK;
 }
@@ -2595,7 +2621,8 @@ int bg_prelu_fwd_t(const void* x, int x_dtype, const float* alpha, void* y, int 
     if (x_dtype == BG_BF16 && y_dtype == BG_BF16 && C % 8 == 0 && rows < (int64_t(1) << 31) && ((uintptr_t)x & 15) == 0 &&
         ((uintptr_t)y & 15) == 0) {
         hipLaunchKernelGGL((prelu_bf16x8_kernel<false>), dim3(bn_x8_grid(rows, C / 8)), dim3(EW_BLOCK), 0, as_stream(stream),
-                           (const __bf16*)x, (const __bf16*)nullptr, alpha, (__bf16*)y, (int)rows, C / 8);
+                           (const __bf16*)x, (const __bf16*)nullptr, alpha, (__bf16*)y, (const __bf16*)nullptr, (int)rows,
+                           C / 8);
         BG_LAUNCH_CHECK();
         return BG_OK;
     }
@@ -2612,25 +2639,27 @@ int bg_prelu_fwd_t(const void* x, int x_dtype, const float* alpha, void* y, int 
 }
 
 int bg_prelu_bwd_t(const void* x, int x_dtype, const void* dy, int y_dtype, const float* alpha, void* dx, float* dalpha,
-                   int64_t rows, int C, void* stream) {
+                   const void* dx_add, int64_t rows, int C, void* stream) {
     BG_REQUIRE(x && dy && alpha && rows > 0 && C > 0 && BG_DT_OK(x_dtype) && BG_DT_OK(y_dtype), "bg_prelu_bwd_t: bad argument");
     const int64_t total = rows * C;
     const bool x8 = x_dtype == BG_BF16 && y_dtype == BG_BF16 && C % 8 == 0 && rows < (int64_t(1) << 31) &&
-                    ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0;
+                    ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0 &&
+                    ((uintptr_t)dx_add & 15) == 0;
     if (dx && x8) {
         hipLaunchKernelGGL((prelu_bf16x8_kernel<true>), dim3(bn_x8_grid(rows, C / 8)), dim3(EW_BLOCK), 0, as_stream(stream),
-                           (const __bf16*)x, (const __bf16*)dy, alpha, (__bf16*)dx, (int)rows, C / 8);
+                           (const __bf16*)x, (const __bf16*)dy, alpha, (__bf16*)dx, (const __bf16*)dx_add, (int)rows, C / 8);
         BG_LAUNCH_CHECK();
     } else if (dx) {
         if (C % 4 == 0)
             BG_DISPATCH_XY(x_dtype, y_dtype,
                            hipLaunchKernelGGL((prelu_bwd_dx_t_kernel<4, TX, TY>), dim3(ew_grid(total / 4)), dim3(EW_BLOCK),
-                                              0, as_stream(stream), (const TX*)x, (const TY*)dy, alpha, (TX*)dx, total / 4,
-                                              C));
+                                              0, as_stream(stream), (const TX*)x, (const TY*)dy, alpha, (TX*)dx,
+                                              (const TX*)dx_add, total / 4, C));
         else
             BG_DISPATCH_XY(x_dtype, y_dtype,
                            hipLaunchKernelGGL((prelu_bwd_dx_t_kernel<1, TX, TY>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0,
-                                              as_stream(stream), (const TX*)x, (const TY*)dy, alpha, (TX*)dx, total, C));
+                                              as_stream(stream), (const TX*)x, (const TY*)dy, alpha, (TX*)dx,
+                                              (const TX*)dx_add, total, C));
         BG_LAUNCH_CHECK();
     }
     if (dalpha) {

@@ -120,6 +120,30 @@ class _Mode:
     inputs_only = False
 
 
+class ForkState:
+    """Shared by the outputs of one ForkFn (ops._fork): the branch whose backward runs first writes its input gradient
+    into a fresh tensor and leaves it here; a later branch whose kernel can add while it writes (conv / transposed-conv
+    input gradients: ``accumulate``; batch-norm and PReLU backward: ``dx_add``) accumulates into that same tensor and
+    hands it back, so ForkFn.backward receives one buffer twice and no separate summing pass runs."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+def _fork_target(fk, like):
+    """(dx, accumulate?) for a branch's input gradient of the forked tensor ``like``."""
+    prev = fk.buf if fk is not None else None
+    if prev is not None and prev.dtype == like.dtype and prev.shape == like.shape and prev.is_contiguous():
+        return prev, True
+    return torch.empty_like(like), False
+
+
+def _fork_done(fk, dx):
+    if fk is not None and dx is not None:
+        fk.buf = dx
+
+
 class KinkProbe:
     """Test instrumentation (tests/test_gpu_step.py): when ``sites`` is a list, every activation launch appends what is
     needed to reconstruct its pre-activation (the tensor itself for a stand-alone PReLU, the batch-norm operands for
@@ -219,7 +243,8 @@ class Conv2dFn(Function):
     bf16 x: the bf16-resident kernels (packed weights, csrc/igemm16.hip); y is bf16 unless ``out_dtype`` says fp32."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad_lo, Ho, Wo, pad_mode, out_dtype=None):
+    def forward(ctx, x, w, bias, stride, pad_lo, Ho, Wo, pad_mode, out_dtype=None, accumulate_into=None):
+        ctx.fork = getattr(x, "bg_fork", None)
         x = _c(x)
         N, H, W_, Cin = x.shape
         k, _, cin2, Cout = w.shape
@@ -228,6 +253,9 @@ class Conv2dFn(Function):
         ctx.resident = _resident_ok(x, Cin, Cout)
         ctx.in_dtype = x.dtype
         ctx.pad8 = None if ctx.resident else _thin_plan(x, Cin, Cout)
+        ctx.acc = accumulate_into is not None
+        if ctx.acc:          # residual sum fused into the epilogue: accumulate_into += conv(x)   (ops.py:313)
+            assert ctx.pad8 is None and tuple(accumulate_into.shape) == (N, Ho, Wo, Cout), "accumulate_into: shape"
         if ctx.pad8 == "in":
             # x8 = [x_hi | x_lo | 0 0]: the image to ~16 mantissa bits in the otherwise idle padding channels;
             # forward and wgrad pair it with the kernel duplicated over the two groups of rows
@@ -261,21 +289,32 @@ class Conv2dFn(Function):
             ydt = out_dtype or BF16
             d = hip.conv_desc(N, H, W_, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode, hip.COMPUTE_BF16, hip.BF16,
                               hip.BF16 if ydt == BF16 else hip.F32, 1)
-            y = torch.empty((N, Ho, Wo, Cout), dtype=ydt, device=x.device)
+            if ctx.acc:
+                y = accumulate_into
+                assert y.dtype == ydt and y.is_contiguous(), (y.dtype, ydt)
+                ctx.mark_dirty(y)
+            else:
+                y = torch.empty((N, Ho, Wo, Cout), dtype=ydt, device=x.device)
             ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, d, x.device)
-            check(L.bg_conv2d_fwd(d, act(x), act(weight_packs(w)[1]), f32(bias), None, act(y), 0, f32(ws), nb, stream()))
+            check(L.bg_conv2d_fwd(d, act(x), act(weight_packs(w)[1]), f32(bias), None, act(y), int(ctx.acc), f32(ws), nb,
+                                  stream()))
             ctx.desc, ctx.rgb = d, False
             ctx.x, ctx.w, ctx.bias = x, w, bias
             return y
         w = _c(w)
         d = hip.conv_desc(N, H, W_, Cin, Ho, Wo, Cout, k, stride, pad_lo, pad_mode, Precision.compute)
-        y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+        if ctx.acc:
+            y = accumulate_into
+            assert y.dtype == torch.float32 and y.is_contiguous()
+            ctx.mark_dirty(y)
+        else:
+            y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         ctx.rgb = bool(L.bg_rgbconv_supported(d))      # <= 3 output channels: direct HBM-bound kernels
         if ctx.rgb:
-            check(L.bg_rgbconv_fwd(d, f32(x), f32(w), f32(bias), f32(y), 0, stream()))
+            check(L.bg_rgbconv_fwd(d, f32(x), f32(w), f32(bias), f32(y), int(ctx.acc), stream()))
         else:
             ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, d, x.device)
-            check(L.bg_conv2d_fwd(d, f32(x), f32(w), f32(bias), None, f32(y), 0, f32(ws), nb, stream()))
+            check(L.bg_conv2d_fwd(d, f32(x), f32(w), f32(bias), None, f32(y), int(ctx.acc), f32(ws), nb, stream()))
         ctx.desc = d
         ctx.x, ctx.w, ctx.bias = x, w, bias
         return y
@@ -326,7 +365,7 @@ class Conv2dFn(Function):
                                             hip.PAD_FOLD, stream()))
             dw = param_grad(w, ctx.needs_input_grad[1], wg8)
             ctx.x = ctx.w = ctx.bias = None
-            return dx, dw, db, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None
         if bias is not None:
             db = param_grad(bias, ctx.needs_input_grad[2], lambda out: _bias_grad(dy.view(-1, d.Cout), out))
         if ctx.resident:
@@ -334,9 +373,11 @@ class Conv2dFn(Function):
             db16 = hip.conv_desc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.k, d.stride, d.pad_lo, d.pad_mode,
                                  hip.COMPUTE_BF16, hip.BF16, hip.BF16, 1)
             if ctx.needs_input_grad[0]:
-                dx = torch.empty_like(x)
+                dx, add = _fork_target(ctx.fork, x)
                 ws, nb = hip.scratch(L.bg_conv2d_dgrad_workspace_bytes, db16, x.device)
-                check(L.bg_conv2d_dgrad(db16, act(dyb), act(weight_packs(w)[0]), None, act(dx), 0, f32(ws), nb, stream()))
+                check(L.bg_conv2d_dgrad(db16, act(dyb), act(weight_packs(w)[0]), None, act(dx), int(add), f32(ws), nb,
+                                        stream()))
+                _fork_done(ctx.fork, dx)
 
             def wg16(out):
                 nb = L.bg_conv2d_wgrad_workspace_bytes(db16)
@@ -344,7 +385,7 @@ class Conv2dFn(Function):
                 check(L.bg_conv2d_wgrad(db16, act(x), act(dyb), f32(out), f32(ws), nb, stream()))
             dw = param_grad(w, ctx.needs_input_grad[1], wg16)
             ctx.x = ctx.w = ctx.bias = None
-            return dx, dw, db, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, (dy if ctx.acc else None)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if ctx.rgb:
@@ -366,7 +407,7 @@ class Conv2dFn(Function):
         ctx.x = ctx.w = ctx.bias = None
         if dx is not None:
             dx = cast(dx, ctx.in_dtype)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, (dy if ctx.acc else None)
 
 
 class Deconv2dFn(Function):
@@ -374,6 +415,7 @@ class Deconv2dFn(Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad_lo, accumulate_into):
+        ctx.fork = getattr(x, "bg_fork", None)
         x = _c(x)
         N, H, W_, Cin = x.shape
         k, _, Cout, cin2 = w.shape
@@ -416,10 +458,12 @@ class Deconv2dFn(Function):
         if ctx.resident:
             dy = cast(dy, BF16)
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            dx, add = _fork_target(ctx.fork if x.dtype == ctx.in_dtype else None, x)
             ws, nb = hip.scratch(L.bg_deconv2d_dgrad_workspace_bytes, d, x.device)
             wk = weight_packs(w)[1] if ctx.resident else w
-            check(L.bg_deconv2d_dgrad(d, act(dy), act(wk), None, act(dx), 0, f32(ws), nb, stream()))
+            check(L.bg_deconv2d_dgrad(d, act(dy), act(wk), None, act(dx), int(add), f32(ws), nb, stream()))
+            if x.dtype == ctx.in_dtype:
+                _fork_done(ctx.fork, dx)
 
         def wg(out):
             nb = L.bg_deconv2d_wgrad_workspace_bytes(d)
@@ -853,6 +897,7 @@ class BnActFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, alpha, moving_mean, moving_var, momentum, eps, unbiased_mv, is_training,
                 reduce_fn, world, renorm=None, out_dtype=None):
+        ctx.fork = getattr(x, "bg_fork", None)
         x = _c(x)
         ydt = out_dtype or x.dtype
         typed = x.dtype != torch.float32 or ydt != torch.float32
@@ -949,11 +994,14 @@ class BnActFn(Function):
             ctx.reduce_fn(cm)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
             if ctx.typed:
+                dx, add = _fork_target(ctx.fork, x)
                 check(L.bg_bn_apply_act_bwd_dx_t(act(x), dt(x), act(dy), dt(dy), f32(mean), f32(rstd), f32(ctx.gamma_c),
-                                                 f32(ctx.beta_c), ps, f32(alpha), f32(cm), act(dx), N, HW, C, stream()))
+                                                 f32(ctx.beta_c), ps, f32(alpha), f32(cm), act(dx), act(dx) if add else None,
+                                                 N, HW, C, stream()))
+                _fork_done(ctx.fork, dx)
             else:
+                dx = torch.empty_like(x)
                 check(L.bg_bn_apply_act_bwd_dx(f32(x), f32(dy), f32(mean), f32(rstd), f32(ctx.gamma_c), f32(ctx.beta_c),
                                                ps, f32(alpha), f32(cm), f32(dx), N, HW, C, stream()))
 
@@ -976,6 +1024,7 @@ class PReluFn(Function):
 
     @staticmethod
     def forward(ctx, x, alpha):
+        ctx.fork = getattr(x, "bg_fork", None)
         x = _c(x)
         C = x.shape[-1]
         if KinkProbe.sites is not None:
@@ -998,18 +1047,21 @@ class PReluFn(Function):
         dx = None
         f32s = x.dtype == torch.float32 and dy.dtype == torch.float32
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
             if f32s:
+                dx = torch.empty_like(x)
                 check(L.bg_prelu_bwd(f32(x), f32(dy), f32(alpha), f32(dx), None, rows, C, stream()))
             else:
-                check(L.bg_prelu_bwd_t(act(x), dt(x), act(dy), dt(dy), f32(alpha), act(dx), None, rows, C, stream()))
+                dx, add = _fork_target(ctx.fork, x)
+                check(L.bg_prelu_bwd_t(act(x), dt(x), act(dy), dt(dy), f32(alpha), act(dx), None, act(dx) if add else None,
+                                       rows, C, stream()))
+                _fork_done(ctx.fork, dx)
 
         def prod(out):
             out.zero_()
             if f32s:
                 check(L.bg_prelu_bwd(f32(x), f32(dy), f32(alpha), None, f32(out), rows, C, stream()))
             else:
-                check(L.bg_prelu_bwd_t(act(x), dt(x), act(dy), dt(dy), f32(alpha), None, f32(out), rows, C, stream()))
+                check(L.bg_prelu_bwd_t(act(x), dt(x), act(dy), dt(dy), f32(alpha), None, f32(out), None, rows, C, stream()))
         da = param_grad(alpha, ctx.needs_input_grad[1], prod)
         ctx.x = None
         return dx, da
@@ -1199,20 +1251,26 @@ class ForkFn(Function):
     autograd engine's own accumulation."""
 
     @staticmethod
-    def forward(ctx, x, n):
+    def forward(ctx, x, n, state=None):
+        ctx.state = state
         return tuple(x.detach().view_as(x) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *gs):
-        gs = [_c(g) for g in gs if g is not None]
-        if not gs:
-            return None, None
-        if len(gs) == 1:
-            return gs[0], None
-        out = add(gs[0], gs[1])
-        for g in gs[2:]:
+        if ctx.state is not None:
+            ctx.state.buf = None
+        uniq = []
+        for g in gs:             # branches that accumulated into the shared buffer (ForkState) hand back the same storage
+            if g is not None and not any(g.data_ptr() == u.data_ptr() and g.shape == u.shape for u in uniq):
+                uniq.append(_c(g))
+        if not uniq:
+            return None, None, None
+        if len(uniq) == 1:
+            return uniq[0], None, None
+        out = add(uniq[0], uniq[1])
+        for g in uniq[2:]:
             out = add(out, g, out=out)
-        return out, None
+        return out, None, None
 
 
 class ScaleAddFn(Function):

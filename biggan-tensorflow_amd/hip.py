@@ -12,7 +12,7 @@ import torch
 
 _LIB = None
 LIB_NAME = "libbiggan_hip.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 PAD_REFLECT, PAD_ZERO = 0, 1
@@ -155,10 +155,10 @@ SIGNATURES = {
     "bg_bn_apply_act_fwd_t": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "bg_bn_apply_act_bwd_reduce_t": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int,
                                              _P]),
-    "bg_bn_apply_act_bwd_dx_t": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int,
+    "bg_bn_apply_act_bwd_dx_t": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int,
                                          _P]),
     "bg_prelu_fwd_t": (c_int, [_P, c_int, _P, _P, c_int, c_int64, c_int, _P]),
-    "bg_prelu_bwd_t": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int64, c_int, _P]),
+    "bg_prelu_bwd_t": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_int64, c_int, _P]),
     "bg_bias_grad_t": (c_int, [_P, c_int, _P, c_int64, c_int, _P]),
     "bg_maxpool2_fwd_t": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bg_maxpool2_bwd_t": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

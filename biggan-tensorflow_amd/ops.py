@@ -149,8 +149,10 @@ def _resident_out(y):
     return y
 
 
-def conv(x, channels, opt, kernel=4, stride=2, pad=0, dilation=1, use_bias=True, scope='conv_0', _out_dtype=None):
-    """ops.py:49-113.  ``_out_dtype`` (extension, bf16-resident mode): element type of the result."""
+def conv(x, channels, opt, kernel=4, stride=2, pad=0, dilation=1, use_bias=True, scope='conv_0', _out_dtype=None,
+         _accumulate_into=None):
+    """ops.py:49-113.  ``_out_dtype`` (extension, bf16-resident mode): element type of the result.
+    ``_accumulate_into`` (extension): add the result into an existing tensor in the kernel epilogue (fused residual sum)."""
     with variable_scope(scope) as full_scope:
         if isinstance(kernel, str):
             raise NotImplementedError("mixed-kernel convolutions (ops.py:52-59) are outside the default hot path")
@@ -195,9 +197,18 @@ def conv(x, channels, opt, kernel=4, stride=2, pad=0, dilation=1, use_bias=True,
         if _is_meta(x):
             return _meta((N, Ho, Wo, channels))
         if _is_dual(x):
-            return Dual(Fn.Conv2dFn.apply(x.p, wk, bias, stride, pad_lo, Ho, Wo, pad_mode),
-                        Fn.Conv2dFn.apply(x.t, wk, None, stride, pad_lo, Ho, Wo, pad_mode))
-        y = Fn.Conv2dFn.apply(x, wk, bias, stride, pad_lo, Ho, Wo, pad_mode, _out_dtype)
+            y = Dual(Fn.Conv2dFn.apply(x.p, wk, bias, stride, pad_lo, Ho, Wo, pad_mode),
+                     Fn.Conv2dFn.apply(x.t, wk, None, stride, pad_lo, Ho, Wo, pad_mode))
+            return y if _accumulate_into is None else _add(y, _accumulate_into)
+        acc = _accumulate_into
+        if acc is not None:
+            # the fused form needs an accumulator of the result's own type and shape that this call may overwrite
+            want = (_out_dtype or (torch.bfloat16 if Fn._resident_ok(x, Cin, channels) else torch.float32))
+            if (acc.dtype != want or not acc.is_contiguous() or Fn._thin_plan(x, Cin, channels) is not None
+                    or (x.dtype == torch.bfloat16 and not Fn._resident_ok(x, Cin, channels))):
+                y = Fn.Conv2dFn.apply(x, wk, bias, stride, pad_lo, Ho, Wo, pad_mode, _out_dtype)
+                return _add(y if _out_dtype is not None else _resident_out(y), acc)
+        y = Fn.Conv2dFn.apply(x, wk, bias, stride, pad_lo, Ho, Wo, pad_mode, _out_dtype, acc)
         return y if _out_dtype is not None else _resident_out(y)
 
 
@@ -282,7 +293,11 @@ def _fork(x, n=2):
         return tuple(Dual(a, b) for a, b in zip(_fork(x.p, n), _fork(x.t, n)))
     if _is_meta(x) or not (torch.is_grad_enabled() and x.requires_grad):
         return (x,) * n
-    return Fn.ForkFn.apply(x, n)
+    state = Fn.ForkState()
+    outs = Fn.ForkFn.apply(x, n, state)
+    for t in outs:
+        t.bg_fork = state        # (the branch gradients meet in one buffer where the kernels can accumulate: ForkState)
+    return outs
 
 
 def resblock(x_init, channels, opt, use_bias=True, scope='resblock'):
@@ -413,10 +428,14 @@ def resblock_down(x_init, channels, opt, use_bias=True, scope='resblock_down'):
             if opt["bn_in_d"]:
                 x = bn(x, opt=opt)
             x = opt["act"](x)
-            x = conv(x, channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
+        # (the skip branch is evaluated before the last main-branch conv so that the residual sum is fused into that
+        #  kernel's epilogue: same values, one pass over the block's output less - as in resblock_up_condition)
         with variable_scope('skip'):
             x_init = downconv(x_init, channels, use_bias=use_bias, opt=opt, method=opt["downsampling_method"])
-    return _add(x, x_init)
+        with variable_scope('res2'):
+            x = conv(x, channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt,
+                     _accumulate_into=None if _is_meta(x) else x_init)
+    return x
 
 
 def _channel_slice(x, lo, hi):

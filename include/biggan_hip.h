@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BG_ABI_VERSION 2
+#define BG_ABI_VERSION 3
 
 enum { BG_OK = 0, BG_ERR_ARG = 1, BG_ERR_LAUNCH = 2, BG_ERR_UNSUPPORTED = 3 };
 enum { BG_PAD_REFLECT = 0, BG_PAD_ZERO = 1 };
@@ -365,12 +365,14 @@ int bg_bn_apply_act_bwd_reduce_t(const void* x, int x_dtype, const void* dy, int
                                  const float* alpha, float* part, int N, int HW, int C, void* stream);
 int bg_bn_apply_act_bwd_dx_t(const void* x, int x_dtype, const void* dy, int y_dtype, const float* mean,
                              const float* rstd, const float* gamma, const float* beta, int per_sample,
-                             const float* alpha, const float* cm, void* dx, int N, int HW, int C, void* stream);
+                             const float* alpha, const float* cm, void* dx, const void* dx_add, int N, int HW, int C,
+                             void* stream);      /* dx_add (x_dtype, nullable, may alias dx): dx = dx_add + gradient - the
+                                                    sum of the two branch gradients of a forked tensor, fused */
 int bg_prelu_fwd_t(const void* x, int x_dtype, const float* alpha, void* y, int y_dtype, int64_t rows, int C,
                    void* stream);
-/* dx (x_dtype, nullable) and / or dalpha (fp32 [C], accumulated: caller zeroes; nullable) */
+/* dx (x_dtype, nullable) and / or dalpha (fp32 [C], accumulated: caller zeroes; nullable); dx_add as above */
 int bg_prelu_bwd_t(const void* x, int x_dtype, const void* dy, int y_dtype, const float* alpha, void* dx,
-                   float* dalpha, int64_t rows, int C, void* stream);
+                   float* dalpha, const void* dx_add, int64_t rows, int C, void* stream);
 int bg_bias_grad_t(const void* dy, int dtype, float* db, int64_t rows, int C, void* stream);
 int bg_maxpool2_fwd_t(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream);
 int bg_maxpool2_bwd_t(const void* x, const void* dy, void* dx, int dtype, int N, int H, int W, int C, void* stream);
