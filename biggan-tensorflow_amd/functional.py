@@ -132,8 +132,9 @@ class ForkState:
 
 
 def _fork_target(fk, like):
-    """(dx, accumulate?) for a branch's input gradient of the forked tensor ``like``."""
-    prev = fk.buf if fk is not None else None
+    """(dx, accumulate?) for a branch's input gradient of the forked tensor ``like``.  (BG_FUSE_FORK=0: A/B switch, every
+    branch writes its own tensor and ForkFn.backward sums them with a separate kernel.)"""
+    prev = fk.buf if (fk is not None and os.environ.get("BG_FUSE_FORK", "1") != "0") else None
     if prev is not None and prev.dtype == like.dtype and prev.shape == like.shape and prev.is_contiguous():
         return prev, True
     return torch.empty_like(like), False

@@ -5,6 +5,8 @@ Tensors are NHWC fp32 CUDA tensors; parameters are created / reused implicitly b
 (``scope.py``).  A tensor on the ``meta`` device only propagates shapes and registers variables
 (used to build the parameter manifest without a GPU); any other non-CUDA tensor raises.
 """
+import os
+
 import torch
 
 from . import functional as Fn
@@ -201,6 +203,9 @@ def conv(x, channels, opt, kernel=4, stride=2, pad=0, dilation=1, use_bias=True,
                      Fn.Conv2dFn.apply(x.t, wk, None, stride, pad_lo, Ho, Wo, pad_mode))
             return y if _accumulate_into is None else _add(y, _accumulate_into)
         acc = _accumulate_into
+        if acc is not None and os.environ.get("BG_FUSE_RESIDUAL", "1") == "0":       # A/B switch: separate add kernel
+            y = Fn.Conv2dFn.apply(x, wk, bias, stride, pad_lo, Ho, Wo, pad_mode, _out_dtype)
+            return _add(y if _out_dtype is not None else _resident_out(y), acc)
         if acc is not None:
             # the fused form needs an accumulator of the result's own type and shape that this call may overwrite
             want = (_out_dtype or (torch.bfloat16 if Fn._resident_ok(x, Cin, channels) else torch.float32))

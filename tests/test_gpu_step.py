@@ -697,6 +697,13 @@ def test_hip_graph_replay_matches_eager_iterations():
         l = gan.train_step(real)
         eager_losses.append((l["d_loss"].item(), l["g_loss"].item()))
     eager_state = {k: v.detach().clone() for k, v in snap.items()}
+    # a second eager run from the same state: its distance to the first is the run-to-run noise floor of the eager path
+    # itself (atomically accumulated reductions; TF-Adam near its epsilon turns 1e-7 of gradient noise into a visible
+    # fraction of a step), which the replayed run is measured against below
+    rewind()
+    for real in reals:
+        gan.train_step(real)
+    eager_again = {k: v.detach().clone() for k, v in snap.items()}
     rewind()
     gan.capture_graphs()
     assert gan._graphs_ready and gan.counter == 0 and gan.d_arena.step == 0
@@ -717,7 +724,9 @@ def test_hip_graph_replay_matches_eager_iterations():
             assert rel < 5e-3, (k, rel)
     for k in snap:
         if k.endswith("/u"):
-            assert torch.allclose(snap[k], eager_state[k], atol=1e-5), k
+            floor = float((eager_again[k] - eager_state[k]).abs().max())
+            got = float((snap[k] - eager_state[k]).abs().max())
+            assert got <= max(1e-5, 4.0 * floor), (k, got, "eager-vs-eager", floor)
 
 
 def test_two_models_in_one_process_do_not_share_variables():
