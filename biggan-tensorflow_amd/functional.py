@@ -195,6 +195,88 @@ def param_grad(t, needed, producer):
     return g
 
 
+def grad_slot(var):
+    """(tensor, accumulate?) where a kernel that can add while it writes delivers d(loss)/d(var) itself (the emit_grad
+    protocol without the temporary): the variable's arena slot, overwritten by the first writer of a step."""
+    slot = getattr(var, "bg_grad", None)
+    if slot is None:
+        if var.grad is None:
+            var.grad = torch.empty(var.shape, dtype=torch.float32, device=var.device)
+            return var.grad, False
+        return var.grad, True
+    acc = bool(var.bg_touched)
+    var.bg_touched = True
+    return slot, acc
+
+
+class ZeroPool:
+    """The zero-initialised accumulators of one run (batch-norm sums, loss sums, regulariser terms: ~60 small tensors) as
+    slices of ONE buffer cleared by ONE fill at the start of the run, instead of a torch.zeros launch each.
+
+    Lifetime rule: a slice handed out in run k may still be READ during run k + 1 - the losses of the D op are returned to
+    the caller and read after the G op has begun; under data parallelism a deferred exchange finishes inside the next
+    run.  So there are TWO buffers used alternately: ``begin_run`` clears and hands out the buffer last used TWO runs
+    ago; the fill is an ordinary kernel on the compute stream, i.e. ordered behind every kernel and every waited-for
+    collective that touched the buffer.  Requests beyond the capacity fall back to torch.zeros and enlarge the pool for
+    the following runs (retired buffers stay referenced: a captured HIP graph may still address them)."""
+
+    def __init__(self, device, nbytes=1 << 19):
+        self.device = torch.device(device)
+        self.cap = int(nbytes)
+        self.bufs = [None, None]
+        self.used = [0, 0]          # bytes handed out from each buffer in its last run (= what the next clear covers)
+        self.cur = 0
+        self.off = 0
+        self.want = 0               # bytes the largest run asked for
+        self.retired = []
+        self.active = False
+
+    def begin_run(self):
+        if self.want > self.cap:
+            self.retired.extend(b for b in self.bufs if b is not None)
+            self.cap = 2 * self.want
+            self.bufs = [None, None]
+            self.used = [0, 0]
+        self.cur ^= 1
+        i = self.cur
+        if self.bufs[i] is None:
+            self.bufs[i] = torch.zeros(self.cap, dtype=torch.uint8, device=self.device)
+        elif self.used[i] > 0:
+            self.bufs[i].narrow(0, 0, self.used[i]).zero_()
+        self.used[i] = 0
+        self.off = 0
+        self.active = True
+
+    def zeros(self, n, dtype):
+        item = torch.empty(0, dtype=dtype).element_size()
+        nbytes = (n * item + 15) // 16 * 16
+        end = self.off + nbytes
+        self.want = max(self.want, end)
+        if not self.active or end > self.cap:
+            self.off = end if self.active else self.off
+            return torch.zeros(n, dtype=dtype, device=self.device)
+        t = self.bufs[self.cur].narrow(0, self.off, n * item).view(dtype)
+        self.off = end
+        self.used[self.cur] = end
+        return t
+
+
+_pool = None
+
+
+def set_zero_pool(pool):
+    """The pool of the model whose run begins (ops.begin_run); None: every request is a torch.zeros."""
+    global _pool
+    _pool = pool
+
+
+def zeros(n, dtype, device):
+    """A zeroed 1-D tensor of ``n`` elements for an accumulator that lives for one run."""
+    if _pool is not None and _pool.device == device and os.environ.get("BG_ZERO_POOL", "1") != "0":
+        return _pool.zeros(n, dtype)
+    return torch.zeros(n, dtype=dtype, device=device)
+
+
 def _bias_grad(dy2d, out):
     if dy2d.dtype == torch.float32:
         check(lib().bg_bias_grad(f32(dy2d), f32(out), dy2d.shape[0], dy2d.shape[1], stream()))
@@ -539,6 +621,71 @@ class DenseFn(Function):
             db = param_grad(bias, ctx.needs_input_grad[2], lambda out: _bias_grad(dy, out))
         ctx.x = ctx.w = ctx.bias = None
         return dx, dw, db
+
+
+class GroupedDenseFn(Function):
+    """n dense projections y_i = x_i w_i + b_i on the same batch rows in ONE launch each way (csrc/dense_group.hip): the
+    beta / gamma projections of the conditional batch norms of a generator block (ops.py:623-624).  Arguments:
+    n, then (x_i, w_i, b_i) flattened; x_i are [B, K_i] row views (column slices allowed) that need no gradient."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        assert len(args) == 3 * n and 1 <= n <= hip.DENSE_GROUP_MAX
+        items = (hip.BgDenseItem * n)()
+        ys, keep = [], []
+        B = args[0].shape[0]
+        for i in range(n):
+            x, w, b = args[3 * i], args[3 * i + 1], args[3 * i + 2]
+            x, ldx = _row_view(x)
+            w = _c(w)
+            assert x.shape[0] == B and w.shape[0] == x.shape[1] and not x.requires_grad
+            y = torch.empty((B, w.shape[1]), dtype=torch.float32, device=x.device)
+            it = items[i]
+            it.x, it.ldx, it.w, it.bias, it.y = x.data_ptr(), ldx, f32(w).value, (f32(b).value if b is not None else None), \
+                y.data_ptr()
+            it.K, it.N = x.shape[1], w.shape[1]
+            ys.append(y)
+            keep.append((x, ldx, w, b))
+        check(lib().bg_dense_group_fwd(items, n, B, stream()))
+        ctx.keep, ctx.B = keep, B
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        if _Mode.inputs_only:
+            return (None,) * (1 + 3 * len(ctx.keep))
+        n = len(ctx.keep)
+        items = (hip.BgDenseItem * n)()
+        m = 0
+        outs = [None]
+        hold = []
+        for i, (x, ldx, w, b) in enumerate(ctx.keep):
+            dy = dys[i]
+            gw = gb = None
+            if dy is not None and ctx.needs_input_grad[2 + 3 * i]:
+                dy = _c(dy)
+                it = items[m]
+                m += 1
+                it.x, it.ldx, it.y, it.K, it.N = x.data_ptr(), ldx, dy.data_ptr(), x.shape[1], w.shape[1]
+                if is_variable(w):
+                    slot, acc = grad_slot(w)
+                else:
+                    slot, acc = torch.empty(w.shape, dtype=torch.float32, device=w.device), False
+                    gw = slot
+                it.dw, it.acc_w = slot.data_ptr(), int(acc)
+                if b is not None and ctx.needs_input_grad[3 + 3 * i]:
+                    if is_variable(b):
+                        bs, bacc = grad_slot(b)
+                    else:
+                        bs, bacc = torch.empty(b.shape, dtype=torch.float32, device=b.device), False
+                        gb = bs
+                    it.db, it.acc_b = bs.data_ptr(), int(bacc)
+                hold.append((dy, slot))
+            outs += [None, gw, gb]
+        if m:
+            check(lib().bg_dense_group_wgrad(items, m, ctx.B, stream()))
+        ctx.keep = None
+        return tuple(outs)
 
 
 class AttentionFn(Function):
@@ -911,7 +1058,7 @@ class BnActFn(Function):
         rstd = torch.empty(C, dtype=torch.float32, device=dev)
         count = float(N * HW * world)
         if is_training:
-            sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+            sums = zeros(2 * C, torch.float64, dev)
             if typed:
                 check(L.bg_bn_stats_t(act(x), dt(x), hip.ptr(sums), N * HW, C, stream()))
             else:
@@ -1578,7 +1725,7 @@ class HingeDLossFn(Function):
         n = real.numel()
         L = lib()
         dev = real.device
-        sums = torch.zeros(2, dtype=torch.float32, device=dev)
+        sums = zeros(2, torch.float32, dev)
         check(L.bg_hinge_d_sums(f32(real), f32(fake), f32(sums), n, stream()))
         if reduce_fn is not None:
             reduce_fn(sums)
@@ -1610,7 +1757,7 @@ class HingeGLossFn(Function):
         n = fake.numel()
         L = lib()
         dev = fake.device
-        sums = torch.zeros(2, dtype=torch.float32, device=dev)
+        sums = zeros(2, torch.float32, dev)
         check(L.bg_hinge_g_sums(f32(fake), f32(sums), n, stream()))
         if reduce_fn is not None:
             reduce_fn(sums)
@@ -1645,11 +1792,11 @@ class GanLossFn(Function):
         real = None if real is None else _c(real)
         L = lib()
         dev = fake.device
-        sums = torch.zeros(2, dtype=torch.float32, device=dev)
+        sums = zeros(2, torch.float32, dev)
         check(L.bg_gan_loss_means(f32(real), f32(fake), f32(sums), nr, nf, stream()))
         if reduce_fn is not None:
             reduce_fn(sums)
-        tsums = torch.zeros(4, dtype=torch.float32, device=dev)
+        tsums = zeros(4, torch.float32, dev)
         check(L.bg_gan_loss_terms(kind, int(generator), f32(real), f32(fake), f32(sums), float(nr * world),
                                   float(nf * world), f32(tsums), nr, nf, stream()))
         if reduce_fn is not None:
@@ -1726,7 +1873,7 @@ class OrthoCosineRegFn(Function):
             gemm(G, W2, P, rows, c, rows, rows, c, c)                                    # P = G W
             ab = torch.empty(2 * c, dtype=torch.float32, device=dev)
             Wb = torch.empty((rows, c), dtype=torch.float32, device=dev)
-            loss = torch.zeros(1, dtype=torch.float32, device=dev)
+            loss = zeros(1, torch.float32, dev)
             check(L.bg_ortho_lowrank_cols(f32(W2), f32(P), f32(s), float(scale), f32(ab), f32(Wb), f32(loss),
                                           rows, c, stream()))
             Wa = torch.empty(rows, dtype=torch.float32, device=dev)
@@ -1753,7 +1900,7 @@ class OrthoCosineRegFn(Function):
             check(L.bg_scale_dev(f32(A), f32(wn.bg_sigma), f32(A), A.numel(), stream()))
         else:
             gemm(W2, W2, A, c, c, rows, c, c, c, transA=True)           # A = W^T W
-        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        loss = zeros(1, torch.float32, dev)
         dA = torch.empty((c, c), dtype=torch.float32, device=dev)
         if kind == "ortho":                                              # utils.py:199-200: reg = A - I
             check(lib().bg_ortho_identity_fwd_bwd(f32(A), float(scale), f32(loss), f32(dA), c, stream()))

@@ -40,6 +40,14 @@ class BgSnItem(Structure):
                 ("pack_p", c_void_p), ("pack_t", c_void_p), ("taps", c_int32), ("pack_p_ld", c_int32)]
 
 
+class BgDenseItem(Structure):
+    _fields_ = [("x", c_void_p), ("ldx", c_int64), ("w", c_void_p), ("bias", c_void_p), ("y", c_void_p), ("dw", c_void_p),
+                ("db", c_void_p), ("K", c_int32), ("N", c_int32), ("acc_w", c_int32), ("acc_b", c_int32)]
+
+
+DENSE_GROUP_MAX = 8
+
+
 class BgAttn16Desc(Structure):
     _fields_ = [(n, c_int32) for n in ("B", "N", "Nk", "d", "dv", "reserved")] + \
                [(n, c_int64) for n in ("ldq", "sq", "ldk", "sk", "ldv", "sv", "ldo", "so",
@@ -74,6 +82,8 @@ SIGNATURES = {
     "bg_rgbconv_dgrad": (c_int, [_CD, _P, _P, _P, c_int, _P]),
     "bg_rgbconv_wgrad_workspace_bytes": (c_size_t, [_CD]),
     "bg_rgbconv_wgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
+    "bg_dense_group_fwd": (c_int, [POINTER(BgDenseItem), c_int, c_int, _P]),
+    "bg_dense_group_wgrad": (c_int, [POINTER(BgDenseItem), c_int, c_int, _P]),
     "bg_gemm_workspace_bytes": (c_size_t, [_GD]),
     "bg_gemm": (c_int, [_GD, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "bg_attention2_supported": (c_int, [c_int, c_int, c_int, c_int]),

@@ -490,7 +490,10 @@ class BigGAN(GANBase):
     def _begin_run(self):
         S.set_default_store(self.store)       # several models may live in one process: ops resolve variables here
         Fn.set_precision(self.precision)
-        ops.begin_run(self._reduce_fn(), self.world, self.rank, getattr(self, "reg_owner", None))
+        if getattr(self, "_zero_pool", None) is None and self.device.type == "cuda":
+            self._zero_pool = Fn.ZeroPool(self.device)
+        ops.begin_run(self._reduce_fn(), self.world, self.rank, getattr(self, "reg_owner", None),
+                      getattr(self, "_zero_pool", None))
 
     def _sn_prefetch(self, group, x):
         if x.is_cuda:
@@ -892,7 +895,7 @@ class BigGAN(GANBase):
                 # the SUM all-reduce of the flat gradient arena then yields the single-process gradient
                 torch.autograd.backward(roots, [ones] * len(roots))
                 self._sn_backward("generator")
-                out["g_reg"] = torch.zeros(1, dtype=torch.float32, device=self.device)
+                out["g_reg"] = Fn.zeros(1, torch.float32, self.device)
                 if out["regs"]:                                     # reported value: column sum of the terms
                     terms = torch.cat([r.detach().reshape(1) for r in out["regs"]]).reshape(-1, 1)
                     Fn._bias_grad(terms, out["g_reg"])

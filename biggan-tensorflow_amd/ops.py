@@ -35,14 +35,20 @@ class _Run:
         self.world = 1
         self.rank = 0
         self.reg_owner = None    # data parallel: variable name -> rank that evaluates its regulariser
+        self.dense_cache = {}    # kernel name -> (x, y) of a dense projection computed ahead by a grouped launch
 
 
 _run = _Run()
 
 
-def begin_run(reduce_fn=None, world=1, rank=0, reg_owner=None):
-    """Start of one ``sess.run``: forget cached spectral norms and regularisation losses."""
+def begin_run(reduce_fn=None, world=1, rank=0, reg_owner=None, zero_pool=None):
+    """Start of one ``sess.run``: forget cached spectral norms and regularisation losses; ``zero_pool``
+    (functional.ZeroPool) serves the run's zero-initialised accumulators from one buffer cleared by one fill."""
     _run.sn_cache = {}
+    _run.dense_cache = {}
+    Fn.set_zero_pool(zero_pool)
+    if zero_pool is not None:
+        zero_pool.begin_run()
     _run.sn_prefetched = set()
     _run.reg_losses = []
     _run.reg_seen = set()
@@ -262,6 +268,9 @@ def fully_connected(x, units, opt, use_bias=True, lrmul=1.0, scope='fully_0'):
             return _meta((x.shape[0], units))
         if _is_dual(x):
             return Dual(Fn.DenseFn.apply(x.p, wk, bias), Fn.DenseFn.apply(x.t, wk, None))
+        hit = _run.dense_cache.pop(w.bg_name, None)
+        if hit is not None and hit[0].data_ptr() == x.data_ptr() and hit[0].shape == x.shape and hit[0].stride() == x.stride():
+            return hit[1]           # computed ahead by the block's grouped launch (_cbn_prefetch)
         return Fn.DenseFn.apply(x, wk, bias)
 
 
@@ -360,6 +369,48 @@ def g_conv(x, channels, opt, use_bias=True, _accumulate_into=None):
         raise ValueError("Invalid generator convolution type specified: " + str(m))
 
 
+def _cbn_prefetch(z, subscopes, opt):
+    """The beta / gamma projections of the conditional batch norms a block is about to evaluate on ``z`` (ops.py:623-624:
+    two fully_connected per condition_batch_norm) as ONE grouped launch (functional.GroupedDenseFn) instead of one GEMM
+    each - and, backward, one launch instead of a weight-gradient, a bias-gradient and a split-K reduce each.
+    ``subscopes``: scopes of the block, relative to the current one, whose 'batch_norm' the block will open.  The results
+    wait in the run's dense cache for the fully_connected calls that would have computed them; anything unusual (first,
+    shape-only pass; non-default batch-norm types; a z that needs a gradient) simply leaves the cache empty."""
+    if z is None or _is_meta(z) or _is_dual(z) or not z.is_cuda or z.requires_grad:
+        return
+    if os.environ.get("BG_GROUP_CBN", "1") == "0":                    # A/B switch
+        return
+    type, bscope = _bn_type(opt, 'batch_norm')
+    if type not in ('bn', 'batch_norm'):
+        return
+    store = S.default_store()
+    base = store.scope_name
+    sn = opt.get("conv", {}).get("sn", True)
+    x = flatten(z)
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32:
+        return
+    args, names = [], []
+    for sub in subscopes:
+        for which in ('beta', 'gamma'):
+            name = "%s/%s/%s/%s" % (base, sub, bscope, which)
+            w, b = store.vars.get(name + "/kernel"), store.vars.get(name + "/bias")
+            if w is None or w.shape[0] != x.shape[1]:
+                return
+            wk = w
+            if sn:
+                cached = _run.sn_cache.get(w.bg_name)
+                if cached is None or cached[1] != (torch.is_grad_enabled() and w.requires_grad):
+                    return
+                wk = cached[0]
+            args += [x, wk, b]
+            names.append(w.bg_name)
+    if not names or len(names) > hip.DENSE_GROUP_MAX:
+        return
+    ys = Fn.GroupedDenseFn.apply(len(names), *args)
+    for nm, y in zip(names, ys):
+        _run.dense_cache[nm] = (x, y)
+
+
 def resblock_up(x_init, channels, opt, use_bias=True, scope='resblock_up'):
     """ops.py:232-248."""
     with variable_scope(scope):
@@ -380,6 +431,7 @@ def resblock_up_condition(x_init, z, channels, opt, use_bias=True, scope='resblo
     """ops.py:250-266.  The skip branch is evaluated before the last main-branch deconv so the
     residual sum is fused into that kernel's epilogue (same values, one pass less)."""
     with variable_scope(scope):
+        _cbn_prefetch(z, ('res1', 'res2'), opt)
         x_main, x_skip = _fork(x_init)
         with variable_scope('res1'):
             x = _bn_act(x_main, z, opt)

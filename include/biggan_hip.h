@@ -137,6 +137,27 @@ size_t bg_gemm_workspace_bytes(const BgGemmDesc*);
 int bg_gemm(const BgGemmDesc*, const float* A, const float* B, const float* bias,
             const float* alpha_dev, float* C, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* Grouped small dense projections on shared batch rows: the beta / gamma fully_connected(z -> C) pairs of the two
+ * conditional batch norms of a generator block (ops.py:623-624 -> ops.py:163-165) as ONE launch per direction.
+ *   fwd  : y_i[b, :] = x_i[b, :K_i] w_i + bias_i             (x_i rows ldx_i floats apart, w_i [K_i, N_i], y_i [B, N_i])
+ *   wgrad: dw_i (+)= x_i^T dy_i, db_i (+)= column sums of dy_i  (y = dy_i; acc_w / acc_b select add vs overwrite; db
+ *          may be NULL).  The items array is HOST memory (copied into the launch), all other pointers device fp32.
+ * No atomics: every output element is produced by one thread in a fixed batch order. */
+#define BG_DENSE_GROUP_MAX 8
+typedef struct BgDenseItem {
+    const float* x;
+    int64_t ldx;
+    const float* w;        /* fwd */
+    const float* bias;     /* fwd, nullable */
+    float* y;              /* fwd: output; wgrad: dy (read) */
+    float* dw;             /* wgrad */
+    float* db;             /* wgrad, nullable */
+    int32_t K, N;
+    int32_t acc_w, acc_b;
+} BgDenseItem;
+int bg_dense_group_fwd(const BgDenseItem* items_host, int n_items, int B, void* stream);
+int bg_dense_group_wgrad(const BgDenseItem* items_host, int n_items, int B, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Fused attention of self_attention_2 (ops.py:481-485): o = softmax(q k^T) v, no 1/sqrt(d) scale.
  *   q [B,N,d], k [B,Nk,d], v [B,Nk,dv], o [B,N,dv], lse [B,N] (= max + log sum exp of each query's

@@ -270,6 +270,40 @@ def test_dense_fwd_bwd(M, K, N):
     assert rel_err(t2n(bc.grad), bt.grad.numpy()) < TOL
 
 
+@pytest.mark.parametrize("B,K,Ns", [(4, 32, (96, 96, 48, 48)), (37, 36, (1536, 1536, 768, 768)), (256, 32, (24, 200)),
+                                    (3, 1032, (64,)), (9, 5, (7, 3, 300))])
+def test_grouped_dense_projections_match_the_separate_ones(B, K, Ns):
+    """functional.GroupedDenseFn (csrc/dense_group.hip): the beta / gamma projections of a generator block's conditional
+    batch norms (ops.py:623-624) in one launch per direction - same values as one fully_connected each (float64
+    reference), weight and bias gradients included, on column slices of a wider z, with and without bias, and
+    accumulating into a gradient that already holds a contribution."""
+    Fn = _fn()
+    rng = np.random.default_rng(B + K + len(Ns))
+    z = rng.standard_normal((B, K + 40))
+    zc = cu(z)
+    xs = zc[:, 8:8 + K]
+    ws = [rng.standard_normal((K, n)) * 0.1 for n in Ns]
+    bs = [rng.standard_normal(n) if i % 3 != 2 else None for i, n in enumerate(Ns)]
+    gs = [rng.standard_normal((B, n)) for n in Ns]
+    wc = [cu(w, True) for w in ws]
+    bc = [None if b is None else cu(b, True) for b in bs]
+    args = []
+    for w_, b_ in zip(wc, bc):
+        args += [xs, w_, b_]
+    ys = Fn.GroupedDenseFn.apply(len(Ns), *args)
+    torch.autograd.backward(list(ys), [cu(g) for g in gs])
+    for i, n in enumerate(Ns):
+        xr = z[:, 8:8 + K]
+        assert rel_err(t2n(ys[i]), xr @ ws[i] + (0 if bs[i] is None else bs[i])) < TOL, i
+        assert rel_err(t2n(wc[i].grad), xr.T @ gs[i]) < TOL, i
+        if bs[i] is not None:
+            assert rel_err(t2n(bc[i].grad), gs[i].sum(0)) < TOL, i
+    # a second backward pass accumulates (the emit_grad protocol: first writer overwrites, later ones add)
+    ys = Fn.GroupedDenseFn.apply(len(Ns), *args)
+    torch.autograd.backward(list(ys), [cu(g) for g in gs])
+    assert rel_err(t2n(wc[0].grad), 2 * (z[:, 8:8 + K].T @ gs[0])) < TOL
+
+
 def test_dense_on_column_slice_without_copy():
     Fn = _fn()
     rng = np.random.default_rng(5)

@@ -129,12 +129,17 @@ def test_abi_rejects_null_tensors_before_any_launch():
                 vals.append(ad)
             elif a is ctypes.c_void_p or a is ctypes.c_char_p:
                 vals.append(None)
+            elif a is ctypes.POINTER(hip.BgDenseItem):
+                items = (hip.BgDenseItem * 2)()          # valid sizes, NULL tensors
+                for it in items:
+                    it.K, it.N, it.ldx = 32, 64, 32
+                vals.append(items)
             elif a in (ctypes.c_float, ctypes.c_double):
                 vals.append(1.0)
             elif a is ctypes.c_size_t:
                 vals.append(1 << 20)
             else:
-                vals.append(128)
+                vals.append(2 if "dense_group" in name and a is ctypes.c_int and len(vals) == 1 else 128)
         rc = getattr(L, name)(*vals)
         assert rc == 1, (name, rc, L.bg_last_error())
         checked += 1
