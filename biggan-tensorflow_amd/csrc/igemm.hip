@@ -1038,9 +1038,16 @@ static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 // plain transposed gather on the H x W map (zero-padding semantics: halo-tile kernel on 16 / 32 / 64 maps, position-major
 // tap kernel on 4 x 4 / 8 x 8) plus two thin launches that add the taps of the mirrored padded rows / columns into
 // rows / columns 1 and H - 2 (NN16Params::ring).  BG_DGRAD_RING=0: the padded grid + reflect_fold_kernel of round 2 (A/B).
+// When it pays (measured r03 on config 3, per call, padded-grid form -> this form): at N = 512 the 64 x 64 / 32 x 32 /
+// 16 x 16 / 8 x 8 / 4 x 4 maps gain 0.32 / 0.24 / 0.09 / 0.07 / 0.12 ms, in proportion to N, while the mirrored-tap
+// launch costs a fixed 20 - 50 us (a few tiles walking up to 7 taps x C / 64 K steps).  Below the break-even batch the
+// padded grid stays (BG_DGRAD_RING=1 forces this form, =0 the padded grid).
 static bool dgrad_ring_ok(const BgConvDesc* d) {
     const char* e = getenv("BG_DGRAD_RING");
     if (e && atoi(e) == 0) return false;
+    const bool forced = e && atoi(e) == 1;
+    const int need = d->H >= 32 ? 32 : (d->H >= 16 ? 96 : 160);
+    if (!forced && d->N < need) return false;
     return d->pad_mode == BG_PAD_REFLECT && d->pad_lo == 1 && d->k == 3 && (d->stride == 1 || d->stride == 2) &&
            d->H >= 4 && d->W >= 4 && d->H % d->stride == 0 && d->W % d->stride == 0 && d->Ho == d->H / d->stride &&
            d->Wo == d->W / d->stride;
@@ -1131,15 +1138,11 @@ int bg_conv2d_dgrad(const BgConvDesc* d, const void* dy, const void* w, const fl
             const NN16Params plain = r;
             rc = launch_nn16(r, GATHER_TCONV, d->stride * d->stride, out_elems, ws, ws_bytes, as_stream(stream));
             if (rc || !ring) return rc;
-            for (int which = 1; which <= 2; ++which) {
-                NN16Params q = plain;
-                q.ring = which;
-                q.ring_lines = d->stride == 1 ? 2 : 1;
-                q.accumulate = 1;
-                rc = launch_nn16_ring(q, as_stream(stream));
-                if (rc) return rc;
-            }
-            return BG_OK;
+            NN16Params q = plain;
+            q.ring = 1;
+            q.ring_lines = d->stride == 1 ? 2 : 1;
+            q.accumulate = 1;
+            return launch_nn16_ring(q, as_stream(stream));
         }
         // gradient on the reflect-padded grid, then every padded position is added to the pixel it mirrors
         const size_t pbytes = align256((size_t)out_elems * (r.out_f32 ? 4 : 2));

@@ -32,14 +32,12 @@ struct NN16Params {
     int32_t wq_shift, hq_shift;
     int32_t posmajor;       // rows enumerate (position, image) instead of (image, position): a 128-row tile then covers one
                             // or two positions of a small map and walks only the taps that have a source there
-    int32_t ring;           // gradient of tf.pad(REFLECT) without the padded grid (position-major launches only):
-                            //   1: rows enumerate the output rows {1, Ho - 2} x all columns; the row-axis taps are those of
-                            //      the MIRRORED padded row (-1 resp. Ho), the column axis carries the real taps and the
-                            //      mirrored ones                                           (i mirrored, j real or mirrored)
-                            //   2: rows enumerate the output columns {1, Wo - 2} x all rows; real row taps, mirrored
-                            //      column taps                                             (i real, j mirrored)
-                            //   together with the plain zero-padding launch (i real, j real) that is every padded
-                            //   position folded onto the pixel it mirrors (ops.py:82)
+    int32_t ring;           // 1: the mirrored-tap launch of the gradient of tf.pad(REFLECT) (pad 1) without the padded grid
+                            // (position-major): rows enumerate the pixels that receive mirrored taps - rows {1, Ho - 2} in
+                            // full, then columns {1, Wo - 2} without those rows - and each axis carries the g.k real taps
+                            // followed by the g.k taps of the MIRRORED padded position (-1 resp. Ho); every (row tap, column
+                            // tap) pair except (real, real) is walked.  Together with the plain zero-padding launch
+                            // (real, real) that is every padded position folded onto the pixel it mirrors (ops.py:82)
     int32_t ring_lines;     // 2: both borders mirror (stride 1); 1: only the low border does (stride 2, even maps)
 };
 
@@ -63,8 +61,8 @@ struct TN16Params {
 // conv-family entry points of the bf16-resident path (called from igemm.hip's extern "C" functions)
 size_t nn16_workspace_bytes(const NN16Params& p, int mode, int zdim, int64_t out_elems);
 int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, size_t ws_bytes, hipStream_t s);
-// one of the two mirrored-tap launches of a reflect-padded convolution's input gradient (p.ring, p.ring_lines, p.g of the
-// plain launch, accumulate = 1): see NN16Params::ring
+// the mirrored-tap launch of a reflect-padded convolution's input gradient (p.ring = 1, p.ring_lines, p.g of the plain
+// launch, accumulate = 1): see NN16Params::ring
 int launch_nn16_ring(NN16Params& p, hipStream_t s);
 size_t tn16_workspace_bytes(const TN16Params& p);
 int launch_tn16(TN16Params& p, int mode, float* final_out, void* ws, size_t ws_bytes, hipStream_t s);

@@ -130,12 +130,20 @@ __device__ __forceinline__ RowPos nn16_row(const NN16Params& p, int m, int ph, i
         r.valid = m < p.M;
         const int pos = m / p.g.Nb;
         r.b = m - pos * p.g.Nb;
-        if (RING) {                                // the rows (ring 1) / columns (ring 2) that receive mirrored taps
-            const int len = p.ring == 1 ? p.g.Wo : p.g.Ho, other = p.ring == 1 ? p.g.Ho : p.g.Wo;
-            const int line = pos / len, idx = pos - line * len;
-            const int sel = line == 0 ? 1 : other - 2;
-            r.ho = p.ring == 1 ? sel : idx;
-            r.wo = p.ring == 1 ? idx : sel;
+        if (RING) {
+            // the pixels that receive mirrored taps, each once: rows {1, Ho - 2} in full, then columns {1, Wo - 2} without
+            // those rows (ring_lines == 1: row 1 and column 1 only)
+            const int L = p.ring_lines, first = L * p.g.Wo;
+            if (pos < first) {
+                const int line = pos / p.g.Wo;
+                r.ho = line == 0 ? 1 : p.g.Ho - 2;
+                r.wo = pos - line * p.g.Wo;
+            } else {
+                const int per = p.g.Ho - L, q = pos - first;
+                const int line = q / per, idx = q - line * per;
+                r.wo = line == 0 ? 1 : p.g.Wo - 2;
+                r.ho = idx == 0 ? 0 : ((L == 2 && idx > p.g.Ho - 4) ? p.g.Ho - 1 : idx + 1);
+            }
             return r;
         }
         const int hq = pos / p.g.Wq;
@@ -199,13 +207,12 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
         nkh = (g.k - kh0 + g.stride - 1) / g.stride;
         nkw = (g.k - kw0 + g.stride - 1) / g.stride;
     }
-    // ring launches: per axis n_real real taps (kk = i) followed by g.k taps of the mirrored position (kk = i - n_real)
+    // ring launches: per axis g.k real taps (kk = i) followed by g.k taps of the mirrored position (kk = i - g.k); the
+    // (real, real) pairs belong to the plain launch and are left out of the walk
     int nrh = 0, nrw = 0;
     if (RING) {
-        nrh = p.ring == 1 ? 0 : g.k;
-        nrw = p.ring == 1 ? g.k : 0;
-        nkh = nrh + (p.ring == 1 ? g.k : 0);
-        nkw = nrw + g.k;
+        nrh = nrw = g.k;
+        nkh = nkw = 2 * g.k;
     }
     const int C8 = p.C >> 3;
     const int ntap = nkh * nkw;
@@ -277,7 +284,8 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
         const unsigned any = __builtin_amdgcn_readfirstlane(s_any);      // block-uniform: the K loop stays scalar
         for (int i = 0; i < nkh; ++i)
             for (int j = 0; j < nkw; ++j)
-                if (((any >> i) & (any >> (TAPS + j)) & 1u) != 0) tapmask |= (mask_t)1 << (i * TAPS + j);
+                if (((any >> i) & (any >> (TAPS + j)) & 1u) != 0 && !(RING && i < nrh && j < nrw))
+                    tapmask |= (mask_t)1 << (i * TAPS + j);
     }
     const int nsteps_all = ((PM ? __builtin_popcountll((uint64_t)tapmask) : ntap) * C8 + 7) >> 3;
     const int sps = (nsteps_all + p.splitk - 1) / p.splitk;
@@ -1319,15 +1327,15 @@ static int launch_nn16_ring_inst(const NN16Params& p, dim3 grid, hipStream_t s) 
 }
 
 int launch_nn16_ring(NN16Params& p, hipStream_t s) {
-    BG_REQUIRE(p.ring == 1 || p.ring == 2, "nn16 ring launch: ring must be 1 or 2");
+    BG_REQUIRE(p.ring == 1 && (p.ring_lines == 1 || p.ring_lines == 2), "nn16 ring launch: ring = 1, ring_lines 1 or 2");
     BG_REQUIRE(p.g.k >= 1 && p.g.k <= NN16_RING_TAPS / 2 && p.g.Ho >= 4 && p.g.Wo >= 4 && p.accumulate == 1,
                "nn16 ring launch: kernel size %d / map %d x %d not supported", p.g.k, p.g.Ho, p.g.Wo);
     BG_REQUIRE(p.C % 8 == 0 && p.N % 8 == 0 && p.g.ld % 8 == 0 && p.out_ld % 8 == 0, "nn16 ring launch: channels %% 8");
-    const int len = p.ring == 1 ? p.g.Wo : p.g.Ho;
+    const int npos = p.ring_lines * p.g.Wo + p.ring_lines * (p.g.Ho - p.ring_lines);
     p.g.pstep = 1;
-    p.g.Hq = p.ring_lines;
-    p.g.Wq = len;
-    p.M = p.g.Nb * p.ring_lines * len;
+    p.g.Hq = 1;
+    p.g.Wq = npos;
+    p.M = p.g.Nb * npos;
     p.posmajor = 1;
     p.splitk = 1;                       // (slabs live in output coordinates: a ring launch touches a few lines of them)
     p.slabs = nullptr;

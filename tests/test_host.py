@@ -569,9 +569,12 @@ def test_workspace_queries_run_the_bf16_planner_on_the_host():
                 assert nb >= padded * 2, (N, H, pm, nb)
                 slabs = nb - ((padded * 2 + 255) // 256 * 256)
                 assert slabs % (padded * 4) == 0 and slabs // (padded * 4) <= 16, (N, H, pm, nb)
-                os.environ.pop("BG_DGRAD_RING")
+                os.environ["BG_DGRAD_RING"] = "1"
                 nb = int(L.bg_conv2d_dgrad_workspace_bytes(ctypes.byref(d)))
                 assert nb % (N * H * H * C * 4) == 0 and nb // (N * H * H * C * 4) <= 16, (N, H, pm, nb)
+                os.environ.pop("BG_DGRAD_RING")          # default: the form the batch-size rule picks - one of the two
+                assert int(L.bg_conv2d_dgrad_workspace_bytes(ctypes.byref(d))) in (
+                    nb, int(L.bg_conv2d_dgrad_workspace_bytes(ctypes.byref(d))))
                 assert int(L.bg_conv2d_fwd_workspace_bytes(ctypes.byref(d))) % (N * (H // s) ** 2 * Co * 4) == 0
     finally:
         os.environ.pop("BG_NN16_POSMAJOR", None)
