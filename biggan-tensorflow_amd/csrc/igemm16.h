@@ -28,6 +28,7 @@ struct NN16Params {
     int64_t slab_stride;
     int32_t tiles_m, tiles_n;
     int32_t zfold;
+    int32_t mfast;          // tile order inside an XCD's share of the grid: 1 = M-tiles fastest (weight slab resident in L2)
     int32_t pow2;           // g.Wq and g.Hq are powers of two: row -> (b, hq, wq) by shifts instead of divisions
     int32_t wq_shift, hq_shift;
     int32_t posmajor;       // rows enumerate (position, image) instead of (image, position): a 128-row tile then covers one

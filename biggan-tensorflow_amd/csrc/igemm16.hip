@@ -182,15 +182,35 @@ __global__ __launch_bounds__(256, 2) void nn16_kernel(const NN16Params p) {
     const int wm = w >> 1, wn = w & 1;
     const Gather& g = p.g;
 
-    int tile, bz = blockIdx.z;
+    // Tile order inside an XCD's contiguous share of the grid (NN16Params::mfast): N-tiles fastest keeps an M-tile's gathered
+    // rows in that L2 while the weight slabs stream past (right when the activations are the big operand); M-tiles fastest
+    // keeps ONE weight slab (one phase, one N-column: <= 1.5 MB) resident while the rows stream (right for the 4 x 4 ...
+    // 16 x 16 layers, whose weights are 5 - 20 x their activations and were re-fetched once per M-tile: 1.9 GB per launch
+    // in round 2's counters).
+    int tile_m, tile_n, bz = blockIdx.z;
     if (p.zfold > 0) {
         const int lin = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.zfold);
-        bz = lin % p.zfold;
-        tile = lin / p.zfold;
+        if (p.mfast) {
+            tile_m = lin % p.tiles_m;
+            const int r_ = lin / p.tiles_m;
+            bz = r_ % p.zfold;
+            tile_n = r_ / p.zfold;
+        } else {
+            bz = lin % p.zfold;
+            const int tile = lin / p.zfold;
+            tile_n = tile % p.tiles_n;
+            tile_m = tile / p.tiles_n;
+        }
     } else {
-        tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+        const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+        if (p.mfast) {
+            tile_m = tile % p.tiles_m;
+            tile_n = tile / p.tiles_m;
+        } else {
+            tile_n = tile % p.tiles_n;
+            tile_m = tile / p.tiles_n;
+        }
     }
-    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int zs = bz % p.splitk, zo = bz / p.splitk;
 
@@ -576,11 +596,20 @@ __global__ __launch_bounds__(512, 4) void nn16h_kernel(const NN16Params p) {    
     const int tiles_x = (g.Wq + NH_T - 1) / NH_T, tiles_y = (g.Hq + NH_T - 1) / NH_T;
     const int nt = (p.N + BN - 1) / BN;
     int r = xcd_remap(blockIdx.x, gridDim.x);
-    const int phase = r % nph; r /= nph;
-    const int tile_n = r % nt; r /= nt;
-    const int tx = r % tiles_x; r /= tiles_x;
-    const int ty = r % tiles_y;
-    const int b = r / tiles_y;
+    int phase, tile_n, tx, ty, b;
+    if (p.mfast) {              // patches fastest: one (phase, N-column) weight slab stays in the XCD's L2 (see nn16_kernel)
+        tx = r % tiles_x; r /= tiles_x;
+        ty = r % tiles_y; r /= tiles_y;
+        b = r % g.Nb; r /= g.Nb;
+        phase = r % nph;
+        tile_n = r / nph;
+    } else {
+        phase = r % nph; r /= nph;
+        tile_n = r % nt; r /= nt;
+        tx = r % tiles_x; r /= tiles_x;
+        ty = r % tiles_y;
+        b = r / tiles_y;
+    }
     const int y0 = ty * NH_T, x0 = tx * NH_T, n0 = tile_n * BN;
     int ph = 0, pw = 0;
     if (MODE == GATHER_TCONV && g.pstep > 1) {
@@ -1317,6 +1346,8 @@ size_t nn16_workspace_bytes(const NN16Params& p, int mode, int zdim, int64_t out
     return pl.splitk > 1 ? (size_t)pl.splitk * out_elems * sizeof(float) : 0;
 }
 
+static int nn16_mfast(const NN16Params& p, int tiles_m, int tiles_n);
+
 // ring launches (NN16Params::ring): mirrored taps of the gradient of tf.pad(REFLECT), accumulated into dx
 template <int TN>
 static int launch_nn16_ring_inst(const NN16Params& p, dim3 grid, hipStream_t s) {
@@ -1348,6 +1379,7 @@ int launch_nn16_ring(NN16Params& p, hipStream_t s) {
     }
     p.tiles_m = (p.M + NN16_BM - 1) / NN16_BM;
     p.tiles_n = (p.N + 32 * tn - 1) / (32 * tn);
+    p.mfast = nn16_mfast(p, p.tiles_m, p.tiles_n);
     dim3 grid(p.tiles_m * p.tiles_n, 1, 1);
     int rc;
     switch (tn) {
@@ -1421,6 +1453,19 @@ static int launch_nn16h_nf(const NN16Params& p, int nf, int blocks, hipStream_t 
     }
 }
 
+// Which operand should stay in an XCD's L2 (4 MB) while the other streams: estimated fabric bytes of the two tile orders.
+// BG_NN16_MFAST=0 / 1 forces one order (A/B).
+static int nn16_mfast(const NN16Params& p, int tiles_m, int tiles_n) {
+    const char* e = getenv("BG_NN16_MFAST");
+    if (e) return atoi(e) != 0;
+    const double l2 = 3.0e6;
+    const double a_bytes = 2.0 * p.g.Nb * (double)p.g.Hs * p.g.Ws * p.g.ld;
+    const double w_bytes = 2.0 * p.g.k * p.g.k * (double)p.N * p.C;
+    const double nfast = a_bytes + (w_bytes > l2 ? w_bytes * tiles_m : w_bytes);
+    const double mfast = w_bytes + (a_bytes > l2 ? a_bytes * tiles_n : a_bytes);
+    return mfast < nfast;
+}
+
 static int launch_nn16h(NN16Params& p, int mode, int ntaps, hipStream_t s) {
     int nf = 4, best = 1 << 30;
     for (int c = 4; c >= 2; --c) {                      // least padded output channels; ties: the wider tile
@@ -1432,6 +1477,7 @@ static int launch_nn16h(NN16Params& p, int mode, int ntaps, hipStream_t s) {
                            (g.pstep * g.pstep);
     BG_REQUIRE(blocks > 0 && blocks < (int64_t(1) << 31), "nn16h: grid out of range");
     p.splitk = 1;
+    p.mfast = nn16_mfast(p, g.Nb * (g.Hq / NH_T) * (g.Wq / NH_T), (p.N + 32 * nf - 1) / (32 * nf));
     int rc;
     if (mode == GATHER_CONV) rc = launch_nn16h_nf<3, GATHER_CONV>(p, nf, (int)blocks, s);
     else if (ntaps == 3) rc = launch_nn16h_nf<3, GATHER_TCONV>(p, nf, (int)blocks, s);
@@ -1467,6 +1513,7 @@ int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, 
         p.hq_shift = __builtin_ctz(p.g.Hq);
     }
     p.posmajor = nn16_posmajor_fraction(p, mode) < 1.0;
+    p.mfast = nn16_mfast(p, p.tiles_m, p.tiles_n);
     dim3 grid(p.tiles_m * p.tiles_n, 1, zdim * p.splitk);
     p.zfold = 0;
     if (mode == GATHER_TCONV && zdim > 1 && p.splitk == 1 && p.g.k % p.g.stride == 0) {
