@@ -1454,10 +1454,15 @@ static int launch_nn16h_nf(const NN16Params& p, int nf, int blocks, hipStream_t 
 }
 
 // Which operand should stay in an XCD's L2 (4 MB) while the other streams: estimated fabric bytes of the two tile orders.
-// BG_NN16_MFAST=0 / 1 forces one order (A/B).
+// OFF by default: measured r03 (config 3, batch 256, same box): N-tiles fastest 100.9 ms / iteration, this rule 102.0, M-tiles
+// fastest everywhere 103.7 - the weight slabs the N-fastest order re-fetches once per M-tile (round 2's FETCH_SIZE counters:
+// 1.9 GB per launch on the 4 x 4 ... 16 x 16 layers) come out of the 256 MB Infinity Cache, not out of HBM, and cost no time,
+// while M-fastest makes every co-resident block miss on its own gathered rows.  BG_NN16_MFAST=auto applies the rule, =1
+// forces M-fastest (for counter runs).
 static int nn16_mfast(const NN16Params& p, int tiles_m, int tiles_n) {
     const char* e = getenv("BG_NN16_MFAST");
-    if (e) return atoi(e) != 0;
+    if (!e) return 0;
+    if (strcmp(e, "auto") != 0) return atoi(e) != 0;
     const double l2 = 3.0e6;
     const double a_bytes = 2.0 * p.g.Nb * (double)p.g.Hs * p.g.Ws * p.g.ld;
     const double w_bytes = 2.0 * p.g.k * p.g.k * (double)p.N * p.C;
