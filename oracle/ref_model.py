@@ -154,7 +154,7 @@ def generator(vs, cfg, z, cls_z=None, is_training=True):
         x = R.fully_connected(vs, first + "/dense1", z_split[zi], f_width, opt)
         x = R.activation(vs, first + "/prelu", x, opt)
         x = R.fully_connected(vs, first + "/dense2", x, 4 * 4 * ch, opt)
-    x = x.reshape(-1, 4, 4, ch)                                             # BigGAN.py:446
+    x = R.r_act(x.reshape(-1, 4, 4, ch))                                    # BigGAN.py:446 (bf16 trunk from here when R.ROUND.on)
 
     b_i = 0
     for block_count in counts:                                              # BigGAN.py:449-489

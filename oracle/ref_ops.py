@@ -16,6 +16,58 @@ import torch.nn.functional as F
 
 
 # ----------------------------------------------------------------------------------
+# optional bf16 rounding points (tests of the product's bf16-resident mode only; OFF = the reference's arithmetic)
+# ----------------------------------------------------------------------------------
+class _Rounding:
+    """The reference computes in fp32 (ops.py:14); the product's ``--precision bf16`` keeps the trunk's activations,
+    their gradients and packed conv weights in bf16.  A float64 oracle therefore differs from that
+    product by bf16 noise (10 - 30 % on first-layer gradients), which hides real errors.  With ``on`` the oracle rounds
+    to bf16 (round-to-nearest-even, torch's conversion = the product's) at the points where the product stores bf16:
+    the output of every conv / transposed conv (after bias and fused residual sum), batch-norm + activation, stand-alone
+    activation, attention and gated residual on NHWC tensors whose channel count is a multiple of 8 (the others stay
+    fp32 in the product too), the spectrally normalised conv kernels that have a packed copy, the attention
+    probabilities - and, backward, the gradient arriving at each of those activation points.  Everything between the
+    rounding points stays float64, so what remains against the product is accumulation order."""
+    on = False
+
+
+ROUND = _Rounding()
+
+
+class _RoundAct(torch.autograd.Function):
+    """A tensor the product stores in bf16 whose gradient it stores in bf16 as well."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """A bf16 copy of an fp32 quantity (packed weights, attention probabilities): the gradient passes unrounded."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _resident(x):
+    """Tensors the product keeps in bf16: 4-D NHWC with a channel count that is a multiple of 8."""
+    return ROUND.on and x.dim() == 4 and x.shape[-1] % 8 == 0
+
+
+def r_act(x):
+    return _RoundAct.apply(x) if _resident(x) else x
+
+
+# ----------------------------------------------------------------------------------
 # variable store (tf.get_variable by full scope name)
 # ----------------------------------------------------------------------------------
 class VarStore:
@@ -199,7 +251,7 @@ def _maybe_regularize(vs, opt, scope, w, kind):
 # ----------------------------------------------------------------------------------
 # conv / deconv / dense   (ops.py:49-175)
 # ----------------------------------------------------------------------------------
-def conv(vs, scope, x, channels, opt, kernel=4, stride=2, pad=0, use_bias=True):
+def conv(vs, scope, x, channels, opt, kernel=4, stride=2, pad=0, use_bias=True, _round_out=True):
     """ops.py:49-113, SN branch.  ``pad>0`` -> total padding 2*pad when H % stride == 0 else
     max(kernel - H % stride, 0), split low = total//2, high = rest (ops.py:65-76); reflect ->
     explicit tf.pad(REFLECT) + VALID conv (ops.py:81-82,94-95); zero -> TF 'SAME'."""
@@ -225,14 +277,16 @@ def conv(vs, scope, x, channels, opt, kernel=4, stride=2, pad=0, use_bias=True):
     w = vs.get(scope + "/kernel", (kernel, kernel, cin, channels), "trunc_normal")
     _maybe_regularize(vs, opt, scope, w, "conv")
     wn = spectral_norm(vs, scope, w) if opt.get("sn", True) else w
+    if ROUND.on and cin % 8 == 0 and channels % 8 == 0:
+        wn = _RoundFwd.apply(wn)                  # the packed bf16 copy of w / sigma (3-channel layers: hi + lo, ~fp32)
     y = F.conv2d(xin, wn.permute(3, 2, 0, 1), stride=stride)
     y = _nhwc(y)
     if use_bias:
         y = y + vs.get(scope + "/bias", (channels,), 0.0)
-    return y
+    return r_act(y) if _round_out else y
 
 
-def deconv(vs, scope, x, channels, opt, kernel=4, stride=2, use_bias=True):
+def deconv(vs, scope, x, channels, opt, kernel=4, stride=2, use_bias=True, _round_out=True):
     """ops.py:116-139: tf.nn.conv2d_transpose(x, SN(w), [B, sH, sW, C], strides s, 'SAME'),
     kernel [k, k, Cout, Cin].  TF's transposed conv is the input-gradient of a SAME conv:
     out[i] += x[a] * w[p] with i = a*s + p - pad_lo, pad_lo = max((H-1)*s + k - s*H, 0)//2, which for
@@ -245,6 +299,8 @@ def deconv(vs, scope, x, channels, opt, kernel=4, stride=2, use_bias=True):
     w = vs.get(scope + "/kernel", (kernel, kernel, channels, cin), "trunc_normal")
     _maybe_regularize(vs, opt, scope, w, "deconv")
     wn = spectral_norm(vs, scope, w) if opt.get("sn", True) else w
+    if ROUND.on and cin % 8 == 0 and channels % 8 == 0:
+        wn = _RoundFwd.apply(wn)
     # torch weight [Cin, Cout, kh, kw]; asymmetric TF padding handled by cropping
     y = F.conv_transpose2d(_nchw(x), wn.permute(3, 2, 0, 1), stride=stride)
     full = y.shape[-1]
@@ -253,7 +309,7 @@ def deconv(vs, scope, x, channels, opt, kernel=4, stride=2, use_bias=True):
     y = _nhwc(y)
     if use_bias:
         y = y + vs.get(scope + "/bias", (channels,), 0.0)
-    return y
+    return r_act(y) if _round_out else y
 
 
 def fully_connected(vs, scope, x, units, opt, use_bias=True, sn=None):
@@ -304,11 +360,11 @@ def activation(vs, scope, x, opt):
         KINK.record.append((scope, x.detach().clone()))
     kind = opt.get("act", "prelu")
     if kind == "prelu":
-        return prelu(vs, scope, x)
+        return r_act(prelu(vs, scope, x))
     if kind == "relu":
-        return torch.relu(x)
+        return r_act(torch.relu(x))
     if kind == "lrelu":
-        return F.leaky_relu(x, 0.2)
+        return r_act(F.leaky_relu(x, 0.2))
     raise ValueError("Unknown activation function: " + str(kind))
 
 
@@ -486,7 +542,7 @@ def resblock(vs, scope, x_init, channels, opt, use_bias=True):
     x = conv(vs, scope + "/res2/conv_0", x, channels, opt, kernel=3, stride=1, pad=1, use_bias=use_bias)
     if opt.get("bn_in_d"):
         x = batch_norm(vs, scope + "/res2/batch_norm", x, opt, True)
-    return x + x_init
+    return r_act(x + x_init)
 
 
 def upconv(vs, scope, x, channels, opt, use_bias=True):
@@ -500,15 +556,16 @@ def upconv(vs, scope, x, channels, opt, use_bias=True):
     return deconv(vs, scope + "/deconv_0", x, channels, opt, kernel=k, stride=2, use_bias=use_bias)
 
 
-def g_conv(vs, scope, x, channels, opt, use_bias=True):
+def g_conv(vs, scope, x, channels, opt, use_bias=True, _round_out=True):
     """ops.py:220-230: --g_conv deconv3 (default) / deconv4 (stride 1) / conv3 (reflect-padded conv)."""
     m = opt.get("g_conv", "deconv3")
     if m == "deconv3":
-        return deconv(vs, scope + "/deconv_0", x, channels, opt, kernel=3, stride=1, use_bias=use_bias)
+        return deconv(vs, scope + "/deconv_0", x, channels, opt, kernel=3, stride=1, use_bias=use_bias, _round_out=_round_out)
     if m == "deconv4":
-        return deconv(vs, scope + "/deconv_0", x, channels, opt, kernel=4, stride=1, use_bias=use_bias)
+        return deconv(vs, scope + "/deconv_0", x, channels, opt, kernel=4, stride=1, use_bias=use_bias, _round_out=_round_out)
     if m == "conv3":
-        return conv(vs, scope + "/conv_0", x, channels, opt, kernel=3, stride=1, pad=1, use_bias=use_bias)
+        return conv(vs, scope + "/conv_0", x, channels, opt, kernel=3, stride=1, pad=1, use_bias=use_bias,
+                    _round_out=_round_out)
     raise ValueError("Invalid generator convolution type specified: " + str(m))
 
 
@@ -519,9 +576,9 @@ def resblock_up_condition(vs, scope, x_init, z, channels, opt, use_bias=True, is
     x = upconv(vs, scope + "/res1", x, channels, opt, use_bias=use_bias)
     x = condition_batch_norm(vs, scope + "/res2/batch_norm", x, z, opt, is_training)
     x = activation(vs, scope + "/res2/prelu", x, opt)
-    x = g_conv(vs, scope + "/res2", x, channels, opt, use_bias=use_bias)
+    x = g_conv(vs, scope + "/res2", x, channels, opt, use_bias=use_bias, _round_out=False)
     skip = upconv(vs, scope + "/skip", x_init, channels, opt, use_bias=use_bias)
-    return x + skip
+    return r_act(x + skip)                      # (the product adds the skip branch in the last kernel's epilogue)
 
 
 def resblock_up_cond_deep(vs, scope, x_init, z, channels_out, opt, upscale=True, use_bias=True, is_training=True):
@@ -598,9 +655,9 @@ def resblock_down(vs, scope, x_init, channels, opt, use_bias=True):
     if opt.get("bn_in_d"):
         x = batch_norm(vs, scope + "/res2/batch_norm", x, opt, True)
     x = activation(vs, scope + "/res2/prelu", x, opt)
-    x = conv(vs, scope + "/res2/conv_0", x, channels, opt, kernel=3, stride=1, pad=1, use_bias=use_bias)
+    x = conv(vs, scope + "/res2/conv_0", x, channels, opt, kernel=3, stride=1, pad=1, use_bias=use_bias, _round_out=False)
     skip = downconv(vs, scope + "/skip", x_init, channels, opt, use_bias=use_bias)
-    return x + skip
+    return r_act(x + skip)
 
 
 def self_attention_2(vs, scope, x, channels, opt):
@@ -614,11 +671,13 @@ def self_attention_2(vs, scope, x, channels, opt):
     hh = max_pooling(hh)
     s = g.reshape(b, -1, g.shape[-1]) @ f.reshape(b, -1, f.shape[-1]).transpose(1, 2)
     beta = torch.softmax(s, dim=-1)
+    if ROUND.on and (channels // 8) % 4 == 0 and (channels // 2) % 8 == 0:
+        beta = _RoundFwd.apply(beta)              # the fused bf16 attention feeds bf16 probabilities to the P V product
     o = beta @ hh.reshape(b, -1, hh.shape[-1])
     gamma = vs.get(scope + "/gamma", (1,), 0.0)
-    o = o.reshape(b, h, w_, channels // 2)
+    o = r_act(o.reshape(b, h, w_, channels // 2))
     o = conv(vs, scope + "/attn_conv", o, channels, opt, kernel=1, stride=1, use_bias=ub)
-    return gamma * o + x
+    return r_act(gamma * o + x)
 
 
 # ----------------------------------------------------------------------------------

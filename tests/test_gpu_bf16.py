@@ -494,6 +494,78 @@ def _bf16_step(mode, img, ch, B):
     print("bf16 step parity [%s %d^2 ch%d]: worst gradient tensor rel. L2 = %.3e" % (mode, img, ch, worst))
 
 
+ROUNDED_GRAD_TOL = 3e-2
+
+
+@pytest.mark.parametrize("img,ch,B", [(64, 16, 4), (128, 96, 2), (256, 16, 2), (512, 16, 1)])
+def test_bf16_step_matches_the_bf16_rounded_oracle(img, ch, B):
+    """THE gate of the bf16-resident mode.  The oracle is run with its optional rounding points on
+    (oracle.ref_ops.ROUND: bf16 where the product stores bf16 - activations, their gradients, packed conv kernels,
+    attention probabilities; float64 in between) and with the activation kinks synchronised to the product's side
+    (tests/test_gpu_step._kink_sync: a pre-activation a few bf16 ulps from 0 may land on either side).  What is left
+    between the two is accumulation order and a handful of values that sit on a bf16 rounding boundary, so EVERY
+    first-step gradient tensor of the D op and of the G op must agree to 3e-2 relative L2 (a missing 30 % term cannot
+    hide in that), losses to 5e-3.  The comparison against the un-rounded float64 oracle (bf16 noise: 10 - 30 % on the
+    first generator layers) is printed as a diagnostic, not gated here (test_bf16_step_close_to_float64_oracle keeps the
+    loose gate).  128^2 / ch 96 is BASELINE config 3's topology and widths; 256^2 and 512^2 (ch 16) are the two-block
+    stages and the generator attention at C = 4 ch (fused bf16 attention, d = 8, dv = 32) of configs 4 and 5."""
+    from oracle import ref_model as RM, ref_ops as R
+    from tests.common import oracle_trainer, hip_model_like, dev_draws
+    from tests.test_gpu_step import _kink_sync
+    from biggan_tensorflow_amd import functional as Fn
+    try:
+        tr = oracle_trainer(img, ch, 64, B)
+        gan = hip_model_like(tr, precision="bf16")
+        batch = RM.synthetic_batch(tr.cfg, 29, B)
+        hip0 = gan.store.export_arrays()
+
+        def compare(tag, run_oracle, run_hip, loss_key):
+            tr.vs.state_updates.clear()
+            gan.store.load_arrays(hip0, reset_ema=False)
+            R.ROUND.on = False
+            plain = run_oracle()                                  # float64, no rounding: the diagnostic
+            tr.vs.state_updates.clear()
+            R.ROUND.on = True
+            try:
+                ro, ho, flips = _kink_sync(tr, run_oracle, run_hip, near=6e-2)
+            finally:
+                R.ROUND.on = False
+            nflip = sum(int(m.sum()) for ms in flips.values() for m in ms if m is not None)
+            lo, lh = ro[loss_key].item(), ho[loss_key].item()
+            errs, errs64 = {}, {}
+            for k, g in ro["grads"].items():
+                if k.endswith("self_attention/f_conv/bias"):      # exactly zero in exact arithmetic
+                    continue
+                gr = g.numpy()
+                if np.linalg.norm(gr) < 1e-12:
+                    continue
+                got = t2n(gan.store.vars[k].bg_grad)
+                errs[k] = rel_err(got, gr)
+                errs64[k] = rel_err(got, plain["grads"][k].numpy())
+            top = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+            print("bf16 vs ROUNDED oracle [%s %d^2 ch%d B%d]: loss %.6f / %.6f, kink elements %d, gradient tensors: "
+                  "median %.2e, worst %s" % (tag, img, ch, B, lh, lo, nflip, float(np.median(list(errs.values()))),
+                                             ", ".join("%s %.3f" % kv for kv in top)))
+            print("   (diagnostic, vs float64 without rounding: median %.2e, worst %.3f)"
+                  % (float(np.median(list(errs64.values()))), max(errs64.values())))
+            assert abs(lh - lo) <= 5e-3 * abs(lo), (tag, lh, lo)
+            loose = {k: e for k, e in errs.items() if k.endswith("self_attention/gamma")}
+            for k, e in errs.items():
+                # the scalar attention gate: <dy, o>, a cancelling dot product of bf16-rounded tensors (|grad| ~ 1e-3 |dy||o|)
+                assert e < (2e-1 if k in loose else ROUNDED_GRAD_TOL), (tag, k, e)
+
+        compare("D op",
+                lambda: tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], apply=False),
+                lambda: gan.d_step(cu(batch["real"]), cu(batch["z_d"]), dev_draws(batch["aug_real"]),
+                                   dev_draws(batch["aug_fake_d"]), apply=False), "d_loss")
+        compare("G op",
+                lambda: tr.g_step(batch["z_g"], batch["aug_fake_g"], apply=False),
+                lambda: gan.g_step(B, cu(batch["z_g"]), dev_draws(batch["aug_fake_g"]), apply=False), "g_loss")
+    finally:
+        R.ROUND.on = False
+        Fn.set_precision("fp32")
+
+
 def _check_grads(gan, ref_grads, tol=4e-1, p90_tol=2e-1, median_tol=1e-1):
     """Every gradient tensor within ``tol`` relative L2 of the float64 oracle, nine tensors in ten within ``p90_tol``
     and the median tensor within ``median_tol``.  The error of a bf16 chain grows with its depth: the first generator
