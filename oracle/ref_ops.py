@@ -277,8 +277,10 @@ def conv(vs, scope, x, channels, opt, kernel=4, stride=2, pad=0, use_bias=True, 
     w = vs.get(scope + "/kernel", (kernel, kernel, cin, channels), "trunc_normal")
     _maybe_regularize(vs, opt, scope, w, "conv")
     wn = spectral_norm(vs, scope, w) if opt.get("sn", True) else w
-    if ROUND.on and cin % 8 == 0 and channels % 8 == 0:
-        wn = _RoundFwd.apply(wn)                  # the packed bf16 copy of w / sigma (3-channel layers: hi + lo, ~fp32)
+    if ROUND.on and channels % 8 == 0 and (cin % 8 == 0 or cin < 8):
+        # the packed bf16 copy of w / sigma.  Image layers: a 3-channel INPUT enters as bf16 value + bf16 residual (~16
+        # bits) against a plain bf16 kernel, so only the kernel rounds; a 3-channel OUTPUT uses a hi + lo kernel (~fp32)
+        wn = _RoundFwd.apply(wn)
     y = F.conv2d(xin, wn.permute(3, 2, 0, 1), stride=stride)
     y = _nhwc(y)
     if use_bias:
@@ -664,18 +666,25 @@ def self_attention_2(vs, scope, x, channels, opt):
     """ops.py:467-492."""
     ub = opt.get("self_attention_bias", False)
     b, h, w_, _ = x.shape
-    f = conv(vs, scope + "/f_conv", x, channels // 8, opt, kernel=1, stride=1, use_bias=ub)
+    # product, bf16-resident mode: when the three projections fit one fused GEMM (widths multiples of 4, their sum a
+    # multiple of 8) f | g | h are ONE bf16 tensor feeding the fused bf16 attention (bf16 probabilities into P V);
+    # otherwise (narrow test models) the projections are written in fp32 and the attention core runs in fp32
+    d_qk, d_v = channels // 8, channels // 2
+    fused = (ROUND.on and x.shape[-1] % 8 == 0 and channels % 8 == 0 and d_v % 8 == 0 and d_qk % 4 == 0
+             and (2 * d_qk + d_v) % 8 == 0)
+    rq = (lambda t: _RoundAct.apply(t)) if fused else (lambda t: t)
+    f = rq(conv(vs, scope + "/f_conv", x, d_qk, opt, kernel=1, stride=1, use_bias=ub, _round_out=False))
     f = max_pooling(f)
-    g = conv(vs, scope + "/g_conv", x, channels // 8, opt, kernel=1, stride=1, use_bias=ub)
-    hh = conv(vs, scope + "/h_conv", x, channels // 2, opt, kernel=1, stride=1, use_bias=ub)
+    g = rq(conv(vs, scope + "/g_conv", x, d_qk, opt, kernel=1, stride=1, use_bias=ub, _round_out=False))
+    hh = rq(conv(vs, scope + "/h_conv", x, d_v, opt, kernel=1, stride=1, use_bias=ub, _round_out=False))
     hh = max_pooling(hh)
     s = g.reshape(b, -1, g.shape[-1]) @ f.reshape(b, -1, f.shape[-1]).transpose(1, 2)
     beta = torch.softmax(s, dim=-1)
-    if ROUND.on and (channels // 8) % 4 == 0 and (channels // 2) % 8 == 0:
-        beta = _RoundFwd.apply(beta)              # the fused bf16 attention feeds bf16 probabilities to the P V product
+    if fused:
+        beta = _RoundFwd.apply(beta)
     o = beta @ hh.reshape(b, -1, hh.shape[-1])
     gamma = vs.get(scope + "/gamma", (1,), 0.0)
-    o = r_act(o.reshape(b, h, w_, channels // 2))
+    o = r_act(o.reshape(b, h, w_, channels // 2)) if (fused or channels % 8 == 0) else o.reshape(b, h, w_, channels // 2)
     o = conv(vs, scope + "/attn_conv", o, channels, opt, kernel=1, stride=1, use_bias=ub)
     return r_act(gamma * o + x)
 
