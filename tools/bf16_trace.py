@@ -76,3 +76,34 @@ for name in order:
         po = np.concatenate(calls, axis=0) if calls else np.zeros(0)
         row.append(float(np.linalg.norm(ph - po) / max(np.linalg.norm(po), 1e-30)) if po.shape == ph.shape else float("nan"))
     print("%-58s %12.3e %12.3e" % (name, row[0], row[1]))
+
+# sign disagreements per site (what the kink synchronisation of the parity tests flips in the oracle)
+print("sign disagreements (ROUNDED oracle):")
+tot = 0
+for name in order:
+    ph = np.concatenate(h_by[name], axis=0)
+    calls = [x.double().numpy() for sc, x in recs[True] if sc == name]
+    po = np.concatenate(calls, axis=0)
+    m = (ph > 0) != (po > 0)
+    n = int(m.sum())
+    tot += n
+    if n:
+        rms = float(np.sqrt(np.mean(po * po)))
+        print("  %-56s %7d of %9d   worst |pre| / rms %.3e" % (name, n, m.size, float(np.abs(po[m]).max()) / rms))
+print("  total", tot)
+
+# gradient tensors in creation (= forward) order: relative L2 distance and projection on the rounded oracle's gradient
+# (kinks NOT synchronised here: sign disagreements above show up as a slightly lower projection)
+R.ROUND.on = True
+tr.vs.state_updates.clear()
+ro = run_o()
+R.ROUND.on = False
+print("%-66s %9s %9s %9s" % ("gradient tensor", "elements", "rel L2", "projection"))
+for k in gan.store.vars:
+    if k not in ro["grads"]:
+        continue
+    gr = ro["grads"][k].numpy().astype(np.float64)
+    if np.linalg.norm(gr) < 1e-12:
+        continue
+    got = t2n(gan.store.vars[k].bg_grad).astype(np.float64)
+    print("%-66s %9d %9.3e %9.4f" % (k, gr.size, np.linalg.norm(got - gr) / np.linalg.norm(gr), (got * gr).sum() / (gr * gr).sum()))
