@@ -427,16 +427,19 @@ def test_two_consecutive_iterations():
         _run_parity(tr, gan, batch)
 
 
-def test_plumbing_config_img64_ch32_batch16():
-    """BASELINE config 1 (plumbing): smallest reference-supported size, ch=32, batch=16, fp32."""
+@pytest.mark.parametrize("seed", [29, 9])
+def test_plumbing_config_img64_ch32_batch16(seed):
+    """BASELINE config 1 (plumbing): smallest reference-supported size, ch=32, batch=16, fp32, with the post-step state
+    check on.  Batch seed 9 is the one round 1 avoided and round 2 stepped around: one generator pre-activation lies within
+    fp32 rounding of the PReLU kink.  With the kink synchronisation it is ONE flipped element, after which every first-step
+    gradient tensor agrees to <= 1.1e-4 (tools/seed9.py prints them: worst generator/self_attention/gamma 1.0e-4, the
+    rest <= 6e-6).  Round 2's remaining 1.1e-3 on generator/first/dense1/kernel does not reproduce with this build; its
+    suspected cause, a near-tie in the attention blocks' 2 x 2 max pools, is measured by the same tool: besides exact
+    ties (windows inside DiffAugment's cutout, where every value is the bias - both sides take the first maximum) the
+    closest pair at this seed is 1e-6 of the tensor's rms apart and both sides pick the same element."""
     tr = oracle_trainer(64, 32, 256, 16)
     gan = hip_model_like(tr)
-    # Batch seeds: round 1 avoided 9 and 39 because one activation each lies within fp32 rounding of the PReLU kink.
-    # With the kink synchronisation (_kink_synced) seed 9 flips exactly that one element and every tensor but ONE then
-    # agrees to <= 1e-4; generator/first/dense1/kernel stays at 1.1e-3 (gate 1e-3) - a second discontinuity that the
-    # probe does not cover (suspected: a near-tie in the attention block's 2x2 max pool; not proven).  Seed 29 has
-    # neither and is used here, with the post-step state check on.
-    batch = RM.synthetic_batch(tr.cfg, 29, 16)
+    batch = RM.synthetic_batch(tr.cfg, seed, 16)
     _run_parity(tr, gan, batch, check_state=True)
 
 
