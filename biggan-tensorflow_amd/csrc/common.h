@@ -70,4 +70,7 @@ void prof_kernel(const char* fmt, ...);
 // Returns false (with the error string set) when the runtime refuses.
 bool lds_opt_in(const void* fn, int bytes);
 
+// sums[c] = sum over rows of part[row][c] (fp32 partial rows -> fp64 sums; elementwise.hip).  sums is zeroed first.
+int launch_partial_colsum(const float* part, double* sums, int64_t rows, int cols, hipStream_t s);
+
 }  // namespace bg

@@ -1255,6 +1255,43 @@ int bg_deconv2d_fwd(const BgConvDesc* d, const void* x, const void* w, const flo
                      d->compute == BG_COMPUTE_BF16);
 }
 
+size_t bg_deconv2d_fwd_stats_workspace_bytes(const BgConvDesc* d) {
+    if (!d || !resident_fwd(d) || d->y_dtype != BG_BF16) return 0;
+    NNParams q;
+    deconv_fwd_params(d, q);
+    NN16Params p;
+    nn16_from(q, p);
+    return (size_t)nn16_stats_rows(p, GATHER_TCONV, d->stride * d->stride) * 2 * (size_t)d->Cout * sizeof(float);
+}
+
+int bg_deconv2d_fwd_stats(const BgConvDesc* d, const void* x, const void* w, const float* bias, const float* alpha_dev,
+                          void* y, int accumulate, double* sums, void* stats_ws, size_t stats_ws_bytes, void* ws,
+                          size_t ws_bytes, void* stream) {
+    int rc = check_deconv(d);
+    if (rc) return rc;
+    BG_REQUIRE(x && w && y && sums && stats_ws, "bg_deconv2d_fwd_stats: null tensor pointer");
+    const size_t need = bg_deconv2d_fwd_stats_workspace_bytes(d);
+    BG_REQUIRE(need > 0 && d->w_packed, "bg_deconv2d_fwd_stats: this launch has no fused statistics (query the workspace)");
+    BG_REQUIRE(stats_ws_bytes >= need && (reinterpret_cast<uintptr_t>(stats_ws) & 15) == 0,
+               "bg_deconv2d_fwd_stats: statistics workspace too small");
+    Tag tag("deconv2d_fwd", d);
+    NNParams p;
+    deconv_fwd_params(d, p);
+    NN16Params r;
+    nn16_from(p, r);
+    r.A = x; r.B = w; r.bias = bias; r.alpha = alpha_dev; r.out = y; r.accumulate = accumulate;
+    r.out_f32 = 0;
+    r.stats_part = reinterpret_cast<float*>(stats_ws);
+    {
+        ProfScope prof(as_stream(stream), conv_flops(d, true), tag.s, tag.bytes);
+        rc = launch_nn16(r, GATHER_TCONV, d->stride * d->stride, (int64_t)d->N * d->Ho * d->Wo * d->Cout, ws, ws_bytes,
+                         as_stream(stream));
+        if (rc) return rc;
+    }
+    return launch_partial_colsum(reinterpret_cast<const float*>(stats_ws), sums, (int64_t)(need / (2 * (size_t)d->Cout * sizeof(float))),
+                                 2 * d->Cout, as_stream(stream));
+}
+
 size_t bg_deconv2d_dgrad_workspace_bytes(const BgConvDesc* d) {
     if (!d) return 0;
     if (resident_dgrad(d)) {

@@ -17,6 +17,8 @@ struct NN16Params {
     const float* alpha;     // device scalar or null
     void* out;              // bf16 or fp32, rows of out_ld elements
     float* slabs;           // split-K partial sums in output coordinates (splitk > 1)
+    float* stats_part;      // halo-tile launches only, nullable: per-block partial batch-norm sums of the stored output,
+                            // rows of [sum (N) | sum of squares (N)], one row per (image, patch, phase)
     Gather g;
     int32_t C;              // channels per tap, multiple of 8 (K = taps * C)
     int32_t M, N;
@@ -62,6 +64,8 @@ struct TN16Params {
 // conv-family entry points of the bf16-resident path (called from igemm.hip's extern "C" functions)
 size_t nn16_workspace_bytes(const NN16Params& p, int mode, int zdim, int64_t out_elems);
 int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, size_t ws_bytes, hipStream_t s);
+// rows of NN16Params::stats_part a launch would write (0: the launch does not take the halo-tile form - no fused statistics)
+int64_t nn16_stats_rows(const NN16Params& p, int mode, int zdim);
 // the mirrored-tap launch of a reflect-padded convolution's input gradient (p.ring = 1, p.ring_lines, p.g of the plain
 // launch, accumulate = 1): see NN16Params::ring
 int launch_nn16_ring(NN16Params& p, hipStream_t s);

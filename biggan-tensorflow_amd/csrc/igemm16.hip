@@ -776,10 +776,15 @@ __global__ __launch_bounds__(512, 4) void nn16h_kernel(const NN16Params p) {    
     __builtin_amdgcn_s_barrier();
 
     // ---- epilogue: accumulators -> LDS [128][BN + 4] fp32 (two halves of the patch) -> 16-byte row segments ----
+    // p.stats_part (batch-norm statistics of the OUTPUT, fused: ops.py:630 tf.nn.moments of the tensor this launch writes):
+    // every stored value, as rounded to its stored type, is written back into the staging tile; the block then reduces the
+    // tile's columns to one row of per-channel partial sums [sum | sum of squares] - summed over blocks in a fixed order by
+    // bn_partial_finalize, no atomics.
     constexpr int ELD = BN + 4;
     float* est = reinterpret_cast<float*>(smem);
     const float alpha = p.alpha ? *p.alpha : 1.0f;
     constexpr int CPR = BN / 8;
+    constexpr int RG = 512 / BN;                        // row groups of the column reduction (threads RG * BN .. 511 idle)
     for (int half = 0; half < 2; ++half) {
         if ((wm >> 1) == half) {                        // waves of pixel rows 8 half .. 8 half + 7
 #pragma unroll
@@ -797,40 +802,82 @@ __global__ __launch_bounds__(512, 4) void nn16h_kernel(const NN16Params p) {    
         for (int idx = t; idx < 128 * CPR; idx += 512) {
             const int row = idx / CPR, cc = idx - row * CPR;
             const int gy = y0 + 8 * half + (row >> 4), gx = x0 + (row & 15), col = n0 + cc * 8;
-            if (gy >= g.Hq || gx >= g.Wq || col >= p.N) continue;
             const int oy = gy * g.pstep + ph, ox = gx * g.pstep + pw;
-            if (oy >= g.Ho || ox >= g.Wo) continue;
-            const int64_t ooff = ((int64_t)(b * g.Ho + oy) * g.Wo + ox) * p.out_ld + col;
             f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(est + row * ELD + cc * 8);
             f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(est + row * ELD + cc * 8 + 4);
-            if (p.bias) {
-                v0 += *reinterpret_cast<const f32x4_t*>(p.bias + col);
-                v1 += *reinterpret_cast<const f32x4_t*>(p.bias + col + 4);
+            const bool live = gy < g.Hq && gx < g.Wq && col < p.N && oy < g.Ho && ox < g.Wo;
+            if (live) {
+                const int64_t ooff = ((int64_t)(b * g.Ho + oy) * g.Wo + ox) * p.out_ld + col;
+                if (p.bias) {
+                    v0 += *reinterpret_cast<const f32x4_t*>(p.bias + col);
+                    v1 += *reinterpret_cast<const f32x4_t*>(p.bias + col + 4);
+                }
+                if (p.out_f32) {
+                    float* o = reinterpret_cast<float*>(p.out) + ooff;
+                    if (p.accumulate) {
+                        v0 += *reinterpret_cast<const f32x4_t*>(o);
+                        v1 += *reinterpret_cast<const f32x4_t*>(o + 4);
+                    }
+                    *reinterpret_cast<f32x4_t*>(o) = v0;
+                    *reinterpret_cast<f32x4_t*>(o + 4) = v1;
+                } else {
+                    __bf16* o = reinterpret_cast<__bf16*>(p.out) + ooff;
+                    if (p.accumulate) {
+                        const uint4 rr = *reinterpret_cast<const uint4*>(o);
+                        v0[0] += bf16_lo(rr.x); v0[1] += bf16_hi(rr.x); v0[2] += bf16_lo(rr.y); v0[3] += bf16_hi(rr.y);
+                        v1[0] += bf16_lo(rr.z); v1[1] += bf16_hi(rr.z); v1[2] += bf16_lo(rr.w); v1[3] += bf16_hi(rr.w);
+                    }
+                    uint4 rr;
+                    rr.x = pack_bf16x2(v0[0], v0[1]);
+                    rr.y = pack_bf16x2(v0[2], v0[3]);
+                    rr.z = pack_bf16x2(v1[0], v1[1]);
+                    rr.w = pack_bf16x2(v1[2], v1[3]);
+                    *reinterpret_cast<uint4*>(o) = rr;
+                    if (p.stats_part) {                 // the values as stored
+                        v0[0] = bf16_lo(rr.x); v0[1] = bf16_hi(rr.x); v0[2] = bf16_lo(rr.y); v0[3] = bf16_hi(rr.y);
+                        v1[0] = bf16_lo(rr.z); v1[1] = bf16_hi(rr.z); v1[2] = bf16_lo(rr.w); v1[3] = bf16_hi(rr.w);
+                    }
+                }
+            } else if (p.stats_part) {
+                v0 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                v1 = v0;
             }
-            if (p.out_f32) {
-                float* o = reinterpret_cast<float*>(p.out) + ooff;
-                if (p.accumulate) {
-                    v0 += *reinterpret_cast<const f32x4_t*>(o);
-                    v1 += *reinterpret_cast<const f32x4_t*>(o + 4);
-                }
-                *reinterpret_cast<f32x4_t*>(o) = v0;
-                *reinterpret_cast<f32x4_t*>(o + 4) = v1;
-            } else {
-                __bf16* o = reinterpret_cast<__bf16*>(p.out) + ooff;
-                if (p.accumulate) {
-                    const uint4 rr = *reinterpret_cast<const uint4*>(o);
-                    v0[0] += bf16_lo(rr.x); v0[1] += bf16_hi(rr.x); v0[2] += bf16_lo(rr.y); v0[3] += bf16_hi(rr.y);
-                    v1[0] += bf16_lo(rr.z); v1[1] += bf16_hi(rr.z); v1[2] += bf16_lo(rr.w); v1[3] += bf16_hi(rr.w);
-                }
-                uint4 rr;
-                rr.x = pack_bf16x2(v0[0], v0[1]);
-                rr.y = pack_bf16x2(v0[2], v0[3]);
-                rr.z = pack_bf16x2(v1[0], v1[1]);
-                rr.w = pack_bf16x2(v1[2], v1[3]);
-                *reinterpret_cast<uint4*>(o) = rr;
+            if (p.stats_part) {
+                *reinterpret_cast<f32x4_t*>(est + row * ELD + cc * 8) = v0;
+                *reinterpret_cast<f32x4_t*>(est + row * ELD + cc * 8 + 4) = v1;
             }
         }
         __syncthreads();
+        if (p.stats_part) {                             // (block-uniform)
+            // column sums of this half's 128 stored rows -> partial row 2 * block + half
+            float st_s = 0.f, st_q = 0.f;
+            if (t < RG * BN) {
+                const int colr = t % BN;
+                for (int row = t / BN; row < 128; row += RG) {
+                    const float v = est[row * ELD + colr];
+                    st_s += v;
+                    st_q = fmaf(v, v, st_q);
+                }
+            }
+            __syncthreads();                            // every read of the tile is done: reuse its first rows
+            if (t < RG * BN) {
+                est[t] = st_s;
+                est[RG * BN + t] = st_q;
+            }
+            __syncthreads();
+            if (t < BN && n0 + t < p.N) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int r2 = 0; r2 < RG; ++r2) {
+                    s += est[r2 * BN + t];
+                    q += est[RG * BN + r2 * BN + t];
+                }
+                const int64_t prow = 2 * ((((int64_t)b * tiles_y + ty) * tiles_x + tx) * nph + phase) + half;
+                p.stats_part[prow * (2 * (int64_t)p.N) + n0 + t] = s;
+                p.stats_part[prow * (2 * (int64_t)p.N) + p.N + n0 + t] = q;
+            }
+            __syncthreads();                            // (the next half overwrites the tile)
+        }
     }
 }
 
@@ -1492,6 +1539,11 @@ static int launch_nn16h(NN16Params& p, int mode, int ntaps, hipStream_t s) {
     return BG_OK;
 }
 
+int64_t nn16_stats_rows(const NN16Params& p, int mode, int zdim) {
+    if (p.C % 8 || p.N % 8 || !nn16h_taps(p, mode, zdim)) return 0;
+    return 2 * (int64_t)p.g.Nb * (p.g.Hq / NH_T) * (p.g.Wq / NH_T) * (p.g.pstep * p.g.pstep);     // one per half patch
+}
+
 int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, size_t ws_bytes, hipStream_t s) {
     BG_REQUIRE(p.C % 8 == 0 && p.N % 8 == 0 && p.g.ld % 8 == 0 && p.out_ld % 8 == 0,
                "bf16-resident conv: channel counts must be multiples of 8 (C=%d N=%d)", p.C, p.N);
@@ -1503,6 +1555,7 @@ int launch_nn16(NN16Params& p, int mode, int zdim, int64_t out_elems, void* ws, 
     BG_REQUIRE((int64_t)p.g.Nb * p.g.Hs * p.g.Ws < (int64_t(1) << 30) && (int64_t)p.g.Nb * p.g.Ho * p.g.Wo < (int64_t(1) << 31),
                "bf16-resident conv: more than 2^30 source / 2^31 output pixels");
     if (const int ntaps = nn16h_taps(p, mode, zdim)) return launch_nn16h(p, mode, ntaps, s);
+    BG_REQUIRE(p.stats_part == nullptr, "bf16-resident conv: fused statistics need the halo-tile form (nn16_stats_rows)");
     NN16Plan pl = plan_nn16(p, mode, zdim, ws != nullptr);
     if (pl.splitk > 1 && ws_bytes < (size_t)pl.splitk * out_elems * sizeof(float)) pl.splitk = 1;
     p.splitk = pl.splitk;

@@ -497,7 +497,9 @@ class Deconv2dFn(Function):
     """tf.nn.conv2d_transpose(SAME)+bias_add (ops.py:127-132); w is [k,k,Cout,Cin]."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad_lo, accumulate_into):
+    def forward(ctx, x, w, bias, stride, pad_lo, accumulate_into, stats_box=None):
+        """``stats_box`` (bf16-resident mode, optional): a one-element list; when the launch can produce the batch-norm
+        sums of its output in its epilogue (bg_deconv2d_fwd_stats) the fp64 [2 Cout] sums tensor is left in it."""
         ctx.fork = getattr(x, "bg_fork", None)
         x = _c(x)
         N, H, W_, Cin = x.shape
@@ -526,7 +528,15 @@ class Deconv2dFn(Function):
         L = lib()
         ws, nb = hip.scratch(L.bg_deconv2d_fwd_workspace_bytes, d, x.device)
         wk = weight_packs(w)[0] if ctx.resident else w
-        check(L.bg_deconv2d_fwd(d, act(x), act(wk), f32(bias), None, act(y), acc, f32(ws), nb, stream()))
+        snb = int(L.bg_deconv2d_fwd_stats_workspace_bytes(d)) if (stats_box is not None and ctx.resident) else 0
+        if snb > 0:
+            sums = zeros(2 * Cout, torch.float64, x.device)
+            sws = workspace(snb, x.device)
+            check(L.bg_deconv2d_fwd_stats(d, act(x), act(wk), f32(bias), None, act(y), acc, hip.ptr(sums), f32(sws), snb,
+                                          f32(ws), nb, stream()))
+            stats_box[0] = sums
+        else:
+            check(L.bg_deconv2d_fwd(d, act(x), act(wk), f32(bias), None, act(y), acc, f32(ws), nb, stream()))
         ctx.desc = d
         ctx.x, ctx.w, ctx.bias = x, w, bias
         ctx.acc = acc
@@ -560,7 +570,7 @@ class Deconv2dFn(Function):
         dacc = dy if ctx.acc else None
         if dx is not None:
             dx = cast(dx, ctx.in_dtype)
-        return dx, dw, db, None, None, dacc
+        return dx, dw, db, None, None, dacc, None
 
 
 # ------------------------------------------------------------------------------------------
@@ -1046,6 +1056,7 @@ class BnActFn(Function):
     def forward(ctx, x, gamma, beta, alpha, moving_mean, moving_var, momentum, eps, unbiased_mv, is_training,
                 reduce_fn, world, renorm=None, out_dtype=None):
         ctx.fork = getattr(x, "bg_fork", None)
+        pre_sums = getattr(x, "bg_bn_sums", None)      # left by the producing kernel's epilogue (Deconv2dFn stats_box)
         x = _c(x)
         ydt = out_dtype or x.dtype
         typed = x.dtype != torch.float32 or ydt != torch.float32
@@ -1058,11 +1069,14 @@ class BnActFn(Function):
         rstd = torch.empty(C, dtype=torch.float32, device=dev)
         count = float(N * HW * world)
         if is_training:
-            sums = zeros(2 * C, torch.float64, dev)
-            if typed:
-                check(L.bg_bn_stats_t(act(x), dt(x), hip.ptr(sums), N * HW, C, stream()))
+            if pre_sums is not None and pre_sums.numel() == 2 * C and os.environ.get("BG_FUSE_BNSTATS", "1") != "0":
+                sums = pre_sums
             else:
-                check(L.bg_bn_stats(f32(x), hip.ptr(sums), N * HW, C, stream()))
+                sums = zeros(2 * C, torch.float64, dev)
+                if typed:
+                    check(L.bg_bn_stats_t(act(x), dt(x), hip.ptr(sums), N * HW, C, stream()))
+                else:
+                    check(L.bg_bn_stats(f32(x), hip.ptr(sums), N * HW, C, stream()))
             if reduce_fn is not None:
                 reduce_fn(sums)
             if renorm is not None:          # corrections first: they read the running statistics before any update
@@ -1194,6 +1208,19 @@ class PReluFn(Function):
         L = lib()
         dx = None
         f32s = x.dtype == torch.float32 and dy.dtype == torch.float32
+        want_da = ctx.needs_input_grad[1] and not _Mode.inputs_only
+        if (ctx.needs_input_grad[0] and want_da and not f32s and is_variable(alpha) and x.dtype == dy.dtype
+                and C % 4 == 0):
+            # dx and dalpha in ONE pass over x and dy (the slope gradient's own reduction read both a second time)
+            dx, add = _fork_target(ctx.fork, x)
+            slot, acc = grad_slot(alpha)
+            if not acc:
+                slot.zero_()
+            check(L.bg_prelu_bwd_t(act(x), dt(x), act(dy), dt(dy), f32(alpha), act(dx), f32(slot), act(dx) if add else None,
+                                   rows, C, stream()))
+            _fork_done(ctx.fork, dx)
+            ctx.x = None
+            return dx, None
         if ctx.needs_input_grad[0]:
             if f32s:
                 dx = torch.empty_like(x)

@@ -73,6 +73,8 @@ SIGNATURES = {
     "bg_conv2d_wgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
     "bg_deconv2d_fwd_workspace_bytes": (c_size_t, [_CD]),
     "bg_deconv2d_fwd": (c_int, [_CD, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "bg_deconv2d_fwd_stats_workspace_bytes": (c_size_t, [_CD]),
+    "bg_deconv2d_fwd_stats": (c_int, [_CD, _P, _P, _P, _P, _P, c_int, _P, _P, c_size_t, _P, c_size_t, _P]),
     "bg_deconv2d_dgrad_workspace_bytes": (c_size_t, [_CD]),
     "bg_deconv2d_dgrad": (c_int, [_CD, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "bg_deconv2d_wgrad_workspace_bytes": (c_size_t, [_CD]),

@@ -530,7 +530,11 @@ class BigGAN(GANBase):
         st = getattr(self, "_g_overlap", None)
         if st is None or not torch.is_grad_enabled() or not getattr(x, "requires_grad", False) or x.device.type != "cuda":
             return x
-        return Fn.GradMarkFn.apply(x, self._g_bucket_done, tag)
+        y = Fn.GradMarkFn.apply(x, self._g_bucket_done, tag)
+        sums = getattr(x, "bg_bn_sums", None)
+        if sums is not None:
+            y.bg_bn_sums = sums            # (fused batch-norm statistics of the block input travel with the marker's view)
+        return y
 
     def _g_bucket_done(self, tag):
         """Backward has passed the input of stage ``tag``: every generator variable from that stage's first slot to the

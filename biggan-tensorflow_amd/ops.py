@@ -223,9 +223,11 @@ def conv(x, channels, opt, kernel=4, stride=2, pad=0, dilation=1, use_bias=True,
         return y if _out_dtype is not None else _resident_out(y)
 
 
-def deconv(x, channels, opt, kernel=4, stride=2, padding='SAME', use_bias=True, scope='deconv_0', _accumulate_into=None):
+def deconv(x, channels, opt, kernel=4, stride=2, padding='SAME', use_bias=True, scope='deconv_0', _accumulate_into=None,
+           _stats=False):
     """ops.py:116-139.  ``_accumulate_into`` (extension): add the result into an existing tensor
-    in the kernel epilogue (fused residual sum)."""
+    in the kernel epilogue (fused residual sum).  ``_stats`` (extension): the result feeds a batch norm - let the kernel
+    leave the per-channel sums of its output on the tensor (``bg_bn_sums``) so the batch norm need not read it again."""
     with variable_scope(scope):
         N, H, W, Cin = x.shape
         if padding != 'SAME':
@@ -243,7 +245,12 @@ def deconv(x, channels, opt, kernel=4, stride=2, padding='SAME', use_bias=True, 
             return _meta((N, H * stride, W * stride, channels))
         if _accumulate_into is not None and _accumulate_into.dtype != x.dtype and x.dtype == torch.bfloat16:
             _accumulate_into = _to(_accumulate_into, x.dtype)
-        return _resident_out(Fn.Deconv2dFn.apply(x, wk, bias, stride, pad_lo, _accumulate_into))
+        box = [None] if (_stats and opt.get("is_training", True) and x.dtype == torch.bfloat16
+                         and os.environ.get("BG_FUSE_BNSTATS", "1") != "0") else None
+        y = _resident_out(Fn.Deconv2dFn.apply(x, wk, bias, stride, pad_lo, _accumulate_into, box))
+        if box is not None and box[0] is not None:
+            y.bg_bn_sums = box[0]
+        return y
 
 
 def get_variable_with_custom_lr(name, shape, regularizer, lrmul):
@@ -309,8 +316,11 @@ def _fork(x, n=2):
         return (x,) * n
     state = Fn.ForkState()
     outs = Fn.ForkFn.apply(x, n, state)
+    sums = getattr(x, "bg_bn_sums", None)
     for t in outs:
         t.bg_fork = state        # (the branch gradients meet in one buffer where the kernels can accumulate: ForkState)
+        if sums is not None:
+            t.bg_bn_sums = sums  # (fused batch-norm statistics of x travel with its branches)
     return outs
 
 
@@ -330,15 +340,18 @@ def resblock(x_init, channels, opt, use_bias=True, scope='resblock'):
         return _add(x, x_skip)
 
 
-def upconv(x, channels, opt, use_bias=True, _accumulate_into=None):
+def upconv(x, channels, opt, use_bias=True, _accumulate_into=None, _stats=False):
     """ops.py:200-218."""
     m = opt["upsampling_method"]
     if m == 'deconv3':
-        return deconv(x, channels, kernel=3, stride=2, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into)
+        return deconv(x, channels, kernel=3, stride=2, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into,
+                      _stats=_stats)
     elif m == 'deconv4':
-        return deconv(x, channels, kernel=4, stride=2, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into)
+        return deconv(x, channels, kernel=4, stride=2, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into,
+                      _stats=_stats)
     elif m == 'deconv6':
-        return deconv(x, channels, kernel=6, stride=2, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into)
+        return deconv(x, channels, kernel=6, stride=2, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into,
+                      _stats=_stats)
     elif m == 'resize_conv':
         x = up_sample(x, 2)
         y = conv(x, channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
@@ -352,13 +365,15 @@ def upconv(x, channels, opt, use_bias=True, _accumulate_into=None):
         raise ValueError("Invalid upsampling method specified: " + str(m))
 
 
-def g_conv(x, channels, opt, use_bias=True, _accumulate_into=None):
+def g_conv(x, channels, opt, use_bias=True, _accumulate_into=None, _stats=False):
     """ops.py:220-230."""
     m = opt["g_conv"]
     if m == 'deconv3':
-        return deconv(x, channels, kernel=3, stride=1, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into)
+        return deconv(x, channels, kernel=3, stride=1, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into,
+                      _stats=_stats)
     elif m == 'deconv4':
-        return deconv(x, channels, kernel=4, stride=1, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into)
+        return deconv(x, channels, kernel=4, stride=1, use_bias=use_bias, opt=opt, _accumulate_into=_accumulate_into,
+                      _stats=_stats)
     elif m == 'conv3':
         y = conv(x, channels, kernel=3, stride=1, pad=1, use_bias=use_bias, opt=opt)
         return y if _accumulate_into is None else _add(y, _accumulate_into)
@@ -435,13 +450,14 @@ def resblock_up_condition(x_init, z, channels, opt, use_bias=True, scope='resblo
         x_main, x_skip = _fork(x_init)
         with variable_scope('res1'):
             x = _bn_act(x_main, z, opt)
-            x = upconv(x, channels, use_bias=use_bias, opt=opt)
+            x = upconv(x, channels, use_bias=use_bias, opt=opt, _stats=True)       # (feeds res2's batch norm)
         with variable_scope('res2'):
             x = _bn_act(x, z, opt)
         with variable_scope('skip'):
             skip = upconv(x_skip, channels, use_bias=use_bias, opt=opt)
         with variable_scope('res2'):
-            x = g_conv(x, channels, use_bias=use_bias, opt=opt, _accumulate_into=skip)
+            # (the block's output feeds the next block's first batch norm, or the generator's last one)
+            x = g_conv(x, channels, use_bias=use_bias, opt=opt, _accumulate_into=skip, _stats=True)
     return x
 
 

@@ -100,6 +100,17 @@ size_t bg_deconv2d_fwd_workspace_bytes(const BgConvDesc*);
 int bg_deconv2d_fwd  (const BgConvDesc*, const void* x, const void* w, const float* bias,
                       const float* alpha_dev, void* y, int accumulate,
                       void* ws, size_t ws_bytes, void* stream);
+/* Transposed-conv forward with the batch-norm statistics of its OUTPUT fused into the epilogue (ops.py:630
+ * tf.nn.moments of the tensor the following condition_batch_norm / batch_norm normalises): sums[0..Cout) = sum of the
+ * stored (bf16-rounded) outputs per channel over (N, Ho, Wo), sums[Cout..2 Cout) = sum of their squares, fp64, zeroed by
+ * the call - what bg_bn_stats_t would compute by reading y again.  Available for the bf16-resident launches that take the
+ * halo-tile form (bf16 y): bg_deconv2d_fwd_stats_workspace_bytes returns the bytes of per-block partial sums the call
+ * needs (stats_ws), 0 when the launch has no fused statistics (callers then use bg_bn_stats_t).  Deterministic: one
+ * partial row per block, summed in fp64. */
+size_t bg_deconv2d_fwd_stats_workspace_bytes(const BgConvDesc*);
+int bg_deconv2d_fwd_stats(const BgConvDesc*, const void* x, const void* w, const float* bias, const float* alpha_dev,
+                          void* y, int accumulate, double* sums, void* stats_ws, size_t stats_ws_bytes, void* ws,
+                          size_t ws_bytes, void* stream);
 size_t bg_deconv2d_dgrad_workspace_bytes(const BgConvDesc*);
 int bg_deconv2d_dgrad(const BgConvDesc*, const void* dy, const void* w, const float* alpha_dev,
                       void* dx, int accumulate, void* ws, size_t ws_bytes, void* stream);

@@ -427,6 +427,39 @@ def test_reflect_conv_input_gradient_without_the_padded_grid(N, H, Cin, Cout, s,
         Fn.set_precision("fp32")
 
 
+@pytest.mark.parametrize("N,H,Cin,Cout,k,s,acc", [(3, 16, 64, 96, 4, 2, False), (2, 32, 96, 96, 3, 1, True),
+                                                    (2, 16, 128, 200, 3, 1, False), (1, 64, 32, 48, 4, 2, True),
+                                                    (2, 8, 64, 64, 4, 2, False)])
+def test_batch_norm_statistics_fused_into_the_deconv_epilogue(N, H, Cin, Cout, k, s, acc):
+    """bg_deconv2d_fwd_stats: the per-channel sum and sum of squares of the transposed conv's STORED (bf16) output, reduced
+    in the kernel's epilogue (ops.py:630 tf.nn.moments of the tensor the next condition_batch_norm reads), against a
+    float64 reduction of the very tensor the launch wrote - with and without the fused residual accumulate, ragged
+    channel counts, both halo forms (3 x 3 and the stride phases of 4 x 4); a map too small for the halo-tile form
+    reports 0 workspace bytes and functional.Deconv2dFn falls back to the separate statistics kernel."""
+    from biggan_tensorflow_amd import functional as Fn, hip
+    Fn.set_precision("bf16")
+    try:
+        g = torch.Generator(device="cuda").manual_seed(N + H + Cin + Cout)
+        x = torch.randn(N, H, H, Cin, device="cuda", generator=g).bfloat16()
+        w = (torch.randn(k, k, Cout, Cin, device="cuda", generator=g) * 0.1)
+        skip = torch.randn(N, H * s, H * s, Cout, device="cuda", generator=g).bfloat16() if acc else None
+        box = [None]
+        y = Fn.Deconv2dFn.apply(x, w, None, s, 1, skip.clone() if acc else None, box)
+        if H < 16:
+            assert box[0] is None                      # (tap kernel: no fused statistics)
+            return
+        assert box[0] is not None and box[0].dtype == torch.float64 and box[0].numel() == 2 * Cout
+        yd = y.double().reshape(-1, Cout)
+        ref = torch.cat([yd.sum(0), (yd * yd).sum(0)])
+        err = float((box[0] - ref).abs().max() / ref.abs().max())
+        assert err < 1e-6, err
+        # and the value itself is what the un-fused launch writes
+        y2 = Fn.Deconv2dFn.apply(x, w, None, s, 1, skip.clone() if acc else None, None)
+        assert torch.equal(y, y2)
+    finally:
+        Fn.set_precision("fp32")
+
+
 @pytest.mark.parametrize("rows,cols,ld", [(9 * 64, 64, 64), (16 * 96, 192, 192), (4608, 384, 384), (200, 24, 120)])
 def test_gram16_from_packed_weights(rows, cols, ld):
     """bg_gram16: W^T W of a bf16 row-major matrix (the regulariser's Gram from the packed copy of w / sigma, also as a
