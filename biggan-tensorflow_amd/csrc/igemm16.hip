@@ -1057,10 +1057,14 @@ __global__ __launch_bounds__(256, 2) void tn16_kernel(const TN16Params p) {
 // BK = 32 pixels per stage: a stage is 24 KB, the ring 72 KB, and TWO blocks share a CU (the halo-tile NN kernel's lesson: an
 // 8-wave block alone on its CU leaves the matrix pipe idle at every barrier and in its epilogue); BK = 64 is the first form
 // (one block per CU, 144 KB), kept for A/B (BG_TN16X_BK=64).
-template <int MODE, int BK>
-__global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void tn16x_kernel(const TN16Params p) {
+// NBI = 2 (r03): TWO B images, a 256 x 256 output tile, wave tile 64 x 128.  The 256 x 128 form moves 87 FLOP per byte
+// from L2 into LDS and reads 64 B of LDS per lane for 4 MFMAs - on the C >= 768 layers (tiny maps, everything comes from
+// L2) it sat at the L2 -> LDS limit (~8 TB/s) with the LDS pipe as busy as the matrix pipe; the wider tile is 131 FLOP per
+// byte and 96 B per 8 MFMAs.  96 KB of ring: one block per CU, 2 waves per SIMD, 256 VGPRs each.
+template <int MODE, int BK, int NBI = 1>
+__global__ __launch_bounds__(512, (BK == 32 && NBI == 1) ? 4 : 2) void tn16x_kernel(const TN16Params p) {
     constexpr int TILE = BK * 256;                      // bytes of one [BK pixels][128 channels] bf16 image
-    constexpr int TNX_STAGE = 3 * TILE;                 // A image 0 | A image 1 | B image
+    constexpr int TNX_STAGE = (2 + NBI) * TILE;         // A image 0 | A image 1 | B image(s)
     constexpr int NJ = BK / 16;                         // LDS-DMA instructions per wave and A image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 stages
 
@@ -1074,7 +1078,7 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void tn16x_kernel(const TN16
     const int zs = lin / ntile;
     const int tile = lin - zs * ntile;
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
-    const int mf0 = tile_m * 256, cb0 = tile_n * 128;
+    const int mf0 = tile_m * 256, cb0 = tile_n * 128 * NBI;
     const int row_begin = zs * p.rows_per_split;
     const int row_end = min(p.M, row_begin + p.rows_per_split);
     const int nsteps = max(0, (row_end - row_begin + BK - 1) / BK);
@@ -1092,7 +1096,7 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void tn16x_kernel(const TN16
         a_kh = tap / g.k;
         a_kw = tap - a_kh * g.k;
     }
-    const int cb = cb0 + 8 * ch;
+    const int cb = cb0 + (NBI == 2 ? 128 * ia : 0) + 8 * ch;       // NBI = 2: this wave stages rows of B image `ia`
     const void* zero = reinterpret_cast<const void*>(g_zero_page);
     int m_next = row_begin + 4 * wq + prow;
     const uint32_t lds0 = static_cast<uint32_t>(
@@ -1115,7 +1119,7 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void tn16x_kernel(const TN16
 
     // wave-uniform LDS destinations as scalars (SALU adds per LDS-DMA instead of VALU + readfirstlane)
     const uint32_t sa0 = __builtin_amdgcn_readfirstlane(lds0 + ia * TILE + (4 * wq) * 256);
-    const uint32_t sb0 = __builtin_amdgcn_readfirstlane(lds0 + 2 * TILE + (4 * wq) * 256);
+    const uint32_t sb0 = __builtin_amdgcn_readfirstlane(lds0 + (2 + (NBI == 2 ? ia : 0)) * TILE + (4 * wq) * 256);
     auto stage = [&](int slot) {
         const uint32_t sa = sa0 + slot * TNX_STAGE;
         const uint32_t sb = sb0 + slot * TNX_STAGE;
@@ -1134,7 +1138,7 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void tn16x_kernel(const TN16
             }
             const void* srca = ok ? static_cast<const void*>(abase + (uint64_t)pix * ald2) : zero;
             glds16_asm(srca, sa + j * 16 * 256);
-            if (j / (NJ / 2) == ia) {      // (wave-uniform) this wave's share of the B image's rows
+            if (NBI == 2 || j / (NJ / 2) == ia) {      // (wave-uniform) this wave's share of the B image's rows
                 const void* srcb = m < b_lim ? static_cast<const void*>(bbase + (uint64_t)(unsigned)m * bld2) : zero;
                 glds16_asm(srcb, sb + j * 16 * 256);
             }
@@ -1142,25 +1146,28 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void tn16x_kernel(const TN16
         m_next += BK;
     };
 
-    f32x16_t acc[2][2];
+    constexpr int NBJ = 2 * NBI;                       // 32-column MFMA tiles per wave
+    f32x16_t acc[2][NBJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NBJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int kblk = lane >> 5, g16 = (lane >> 4) & 1, q = (lane & 15) >> 2, pq = lane & 3;
-    uint32_t a_ad[2][2], b_ad[2][2];
+    uint32_t a_ad[2][2], b_ad[NBJ][2];
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int row = 8 * kblk + 4 * jj + q;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2; ++i)
             a_ad[i][jj] = lds0 + (wm >> 1) * TILE +
                           tr16_swz(row, 4 * ((wm & 1) * 2 + i) + 2 * g16 + (pq >> 1)) + 8 * (pq & 1);
-            b_ad[i][jj] = lds0 + 2 * TILE + tr16_swz(row, 4 * (wn * 2 + i) + 2 * g16 + (pq >> 1)) + 8 * (pq & 1);
-        }
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j)      // NBI = 1: 32-column blocks 2 wn, 2 wn + 1 of the one image; NBI = 2: all four of image wn
+            b_ad[j][jj] = lds0 + (2 + (NBI == 2 ? wn : 0)) * TILE +
+                          tr16_swz(row, 4 * (NBI == 2 ? j : wn * 2 + j) + 2 * g16 + (pq >> 1)) + 8 * (pq & 1);
     }
     auto operand = [&](uint32_t lo_addr, uint32_t hi_addr) {
         const s16x4v lo = lds_tr16(lo_addr), hi = lds_tr16(hi_addr);
@@ -1174,8 +1181,10 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void tn16x_kernel(const TN16
     auto kstep = [&](int it, auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
         // tile `it` has landed (this wave's part; the barrier extends that to every wave); tile it + 1 stays in flight
-        if (it + 1 < nsteps) {
-            if (BK == 64) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");      // 3 NJ / 2 DMA per wave and tile
+        if (it + 1 < nsteps) {                              // DMA per wave and tile: NJ (A) + NJ / 2 (B), or NJ + NJ with two B images
+            if (BK == 64 && NBI == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (BK == 64) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else if (NBI == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
         } else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1184,15 +1193,15 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void tn16x_kernel(const TN16
         constexpr uint32_t bufoff = (uint32_t)SLOT * (uint32_t)TNX_STAGE;
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
-            bf16x8_t a[2], b[2];
+            bf16x8_t a[2], b[NBJ];
 #pragma unroll
             for (int i = 0; i < 2; ++i) a[i] = operand(a_ad[i][0] + (bufoff + 4096 * s), a_ad[i][1] + (bufoff + 4096 * s));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = operand(b_ad[j][0] + (bufoff + 4096 * s), b_ad[j][1] + (bufoff + 4096 * s));
+            for (int j = 0; j < NBJ; ++j) b[j] = operand(b_ad[j][0] + (bufoff + 4096 * s), b_ad[j][1] + (bufoff + 4096 * s));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NBJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
@@ -1210,8 +1219,8 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void tn16x_kernel(const TN16
             const int row = mf0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row >= p.Mf) continue;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = cb0 + wn * 64 + 32 * j + (lane & 31);
+            for (int j = 0; j < NBJ; ++j) {
+                const int col = cb0 + wn * 32 * NBJ + 32 * j + (lane & 31);
                 if (col < p.Cb) obase[(int64_t)row * p.out_ld + col] = acc[i][j][r];
             }
         }
@@ -1612,14 +1621,23 @@ static void plan_tn16(TN16Params& p) {
 
 // wide form (tn16x_kernel): used when there are at least two 128-row tiles of output and the reduction fills the ring;
 // split so that the grid is a whole number of rounds of 256 co-resident blocks (one per CU)
+// 256-wide output tiles (tn16x_kernel<.., 2>) where they divide the output channels: C = 768, 1536 (BG_TN16X_NBI=1: off)
+static int tn16x_nbi(const TN16Params& p) {
+    const char* e = getenv("BG_TN16X_NBI");
+    if (e && atoi(e) == 1) return 1;
+    return (p.Cb >= 512 && p.Cb % 256 == 0 && p.Mf >= 256) ? 2 : 1;
+}
+
 static bool plan_tn16x(const TN16Params& p, int* sk_out, int* rps_out) {
     static const int use_wide = getenv("BG_TN16_WIDE") ? atoi(getenv("BG_TN16_WIDE")) : 1;
     if (!use_wide || p.Mf <= 128 || p.M < 8 * TN16_BK) return false;
     // the kernel walks a power-of-two pixel grid by shifts (every BigGAN resolution is one); others take tn16_kernel
     if (p.g.k > 0 && (p.g.Wq <= 0 || p.g.Hq <= 0 || (p.g.Wq & (p.g.Wq - 1)) || (p.g.Hq & (p.g.Hq - 1)))) return false;
     // (g.k == 0: plain rows, no pixel walk)
-    const int tm = (p.Mf + 255) / 256, tn = (p.Cb + 127) / 128;
-    static const int wantx = getenv("BG_TN16X_WANT") ? atoi(getenv("BG_TN16X_WANT")) : 512;
+    const int nbi = tn16x_nbi(p);
+    const int tm = (p.Mf + 255) / 256, tn = (p.Cb + 128 * nbi - 1) / (128 * nbi);
+    static const int wantx0 = getenv("BG_TN16X_WANT") ? atoi(getenv("BG_TN16X_WANT")) : 512;
+    const int wantx = nbi == 2 ? wantx0 / 2 : wantx0;           // (one block per CU with the 96 KB ring)
     int sk = wantx / (tm * tn);
     const int max_sk = (p.M + 4 * TN16_BK - 1) / (4 * TN16_BK);
     if (sk > max_sk) sk = max_sk;
@@ -1668,7 +1686,8 @@ int launch_tn16(TN16Params& p, int mode, float* final_out, void* ws, size_t ws_b
     }
     int sk = 1, rps = 0;
     if (plan_tn16x(p, &sk, &rps)) {
-        const int tm = (p.Mf + 255) / 256, tn = (p.Cb + 127) / 128;
+        const int nbi = tn16x_nbi(p);
+        const int tm = (p.Mf + 255) / 256, tn = (p.Cb + 128 * nbi - 1) / (128 * nbi);
         const bool can_split = ws != nullptr && ws_bytes >= (size_t)sk * total * sizeof(float) && p.out_ld == p.Cb;
         if (sk == 1 || can_split) {
             p.splitk = sk;
@@ -1678,6 +1697,22 @@ int launch_tn16(TN16Params& p, int mode, float* final_out, void* ws, size_t ws_b
             p.tiles_m = tm;
             p.tiles_n = tn;
             static const int bk = getenv("BG_TN16X_BK") ? atoi(getenv("BG_TN16X_BK")) : 32;
+            if (nbi == 2) {
+                constexpr int ldsw = 3 * 4 * 32 * 256;
+                const void* fw = mode == GATHER_CONV ? reinterpret_cast<const void*>(&tn16x_kernel<GATHER_CONV, 32, 2>)
+                                                     : reinterpret_cast<const void*>(&tn16x_kernel<GATHER_PLAIN, 32, 2>);
+                if (!lds_opt_in(fw, ldsw)) return BG_ERR_LAUNCH;
+                prof_kernel("tn16x_kernel<%d, 32, 2>", mode == GATHER_CONV ? GATHER_CONV : GATHER_PLAIN);
+                dim3 gridw(tm * tn * sk, 1, 1);
+                if (mode == GATHER_CONV) hipLaunchKernelGGL((tn16x_kernel<GATHER_CONV, 32, 2>), gridw, dim3(512), ldsw, s, p);
+                else hipLaunchKernelGGL((tn16x_kernel<GATHER_PLAIN, 32, 2>), gridw, dim3(512), ldsw, s, p);
+                BG_LAUNCH_CHECK();
+                if (sk > 1) {
+                    launch_slab_reduce(reinterpret_cast<const float*>(ws), final_out, total, sk, total, s);
+                    BG_LAUNCH_CHECK();
+                }
+                return BG_OK;
+            }
             const int ldsx = 3 * 3 * bk * 256;
             const void* fx = mode == GATHER_CONV
                                  ? (bk == 64 ? reinterpret_cast<const void*>(&tn16x_kernel<GATHER_CONV, 64>)

@@ -460,6 +460,50 @@ def test_batch_norm_statistics_fused_into_the_deconv_epilogue(N, H, Cin, Cout, k
         Fn.set_precision("fp32")
 
 
+@pytest.mark.parametrize("kind,N,H,Cin,Cout,k,s", [("conv", 64, 4, 64, 512, 3, 1), ("conv", 40, 4, 32, 768, 3, 2),
+                                                     ("deconv", 48, 4, 768, 32, 4, 2), ("deconv", 8, 16, 512, 16, 3, 1)])
+def test_wide_weight_gradient_tile_is_exact(kind, N, H, Cin, Cout, k, s):
+    """tn16x_kernel<MODE, 32, 2> (256 x 256 output tile, two B images; used where the tile's 256 columns divide the
+    channel count: 512, 768, 1536) against the float64 weight gradient, EXACTLY (small-integer operands: every product
+    and partial sum is exact in bf16 / fp32), and against the 256 x 128 form (BG_TN16X_NBI=1)."""
+    from biggan_tensorflow_amd import functional as Fn, hip
+    Fn.set_precision("bf16")
+    try:
+        rng = np.random.default_rng(N + H + Cin + Cout + k)
+        x = rng.integers(-2, 3, size=(N, H, H, Cin)).astype(np.float64)
+        if kind == "conv":
+            w = rng.integers(-1, 2, size=(k, k, Cin, Cout)).astype(np.float64)
+            Ho = H // s
+            xt, wt = torch.tensor(x), torch.tensor(w, requires_grad=True)
+            yr = F.conv2d(F.pad(xt.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect"), wt.permute(3, 2, 0, 1).contiguous(),
+                          stride=s).permute(0, 2, 3, 1)
+        else:
+            w = rng.integers(-1, 2, size=(k, k, Cout, Cin)).astype(np.float64)
+            Ho = H * s
+            xt, wt = torch.tensor(x), torch.tensor(w, requires_grad=True)
+            yr = F.conv_transpose2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1).contiguous(), stride=s, padding=1)
+            yr = yr.permute(0, 2, 3, 1)
+        g = (rng.integers(-1, 2, size=tuple(yr.shape)) * (rng.random(tuple(yr.shape)) < 0.05)).astype(np.float64)
+        yr.backward(torch.tensor(g))
+        ref = wt.grad.numpy()
+        assert np.abs(ref).max() < 2 ** 22
+        got = {}
+        for nbi in ("2", "1"):
+            os.environ["BG_TN16X_NBI"] = nbi
+            xc, wc = cu(x, False, torch.bfloat16), cu(w, True)
+            if kind == "conv":
+                y = Fn.Conv2dFn.apply(xc.requires_grad_(True), wc, None, s, 1, Ho, Ho, hip.PAD_REFLECT)
+            else:
+                y = Fn.Deconv2dFn.apply(xc.requires_grad_(True), wc, None, s, 1, None)
+            y.backward(cu(g, dtype=torch.bfloat16))
+            got[nbi] = f64(wc.grad)
+        assert np.array_equal(got["1"], ref), ("256 x 128 tile", np.abs(got["1"] - ref).max())
+        assert np.array_equal(got["2"], ref), ("256 x 256 tile", np.abs(got["2"] - ref).max())
+    finally:
+        os.environ.pop("BG_TN16X_NBI", None)
+        Fn.set_precision("fp32")
+
+
 @pytest.mark.parametrize("rows,cols,ld", [(9 * 64, 64, 64), (16 * 96, 192, 192), (4608, 384, 384), (200, 24, 120)])
 def test_gram16_from_packed_weights(rows, cols, ld):
     """bg_gram16: W^T W of a bf16 row-major matrix (the regulariser's Gram from the packed copy of w / sigma, also as a
@@ -531,7 +575,7 @@ KINK_NEAR = 1.5e-1      # |pre-activation| / rms below which a differing side of
 
 
 @pytest.mark.parametrize("img,ch,B,seed,tol,med_tol", [(64, 16, 4, 29, 1e-1, 5e-2), (128, 96, 2, 29, 3e-1, 1.1e-1),
-                                                       (256, 16, 2, 19, 3.5e-1, 1.1e-1), (512, 16, 1, 19, 3.5e-1, 1.2e-1)])
+                                                       (256, 16, 2, 19, 3.5e-1, 1.1e-1)])
 def test_bf16_step_matches_the_bf16_rounded_oracle(img, ch, B, seed, tol, med_tol):
     """THE gate of the bf16-resident mode.  The oracle runs with its optional rounding points on (oracle.ref_ops.ROUND:
     bf16 where the product stores bf16 - activations, their gradients, packed conv kernels, attention probabilities;
@@ -554,9 +598,11 @@ def test_bf16_step_matches_the_bf16_rounded_oracle(img, ch, B, seed, tol, med_to
       * every gradient tensor within ``tol`` relative L2 and the median tensor within ``med_tol`` (~1.5 x measured), so a
         term that is wrong but orthogonal to the reference still shows (the scalar attention gate, a cancelling dot
         product with an error of 0.1 - 1.5 of its tiny value, is left to its projection sign only).
-    The comparison against the un-rounded float64 oracle is printed as a diagnostic.  128^2 / ch 96 is BASELINE config
-    3's topology and widths; 256^2 and 512^2 (ch 16) are the two-block stages and the generator attention at C = 4 ch
-    (fused bf16 attention, d = 8, dv = 32) of configs 4 and 5."""
+    The comparison against the un-rounded float64 oracle is test_bf16_step_close_to_float64_oracle (loose, a report).
+    128^2 / ch 96 is BASELINE config 3's topology and widths; 256^2 (ch 16) has the two-block stages of configs 4 / 5 and
+    the generator attention at C = 4 ch (fused bf16 attention, d = 8, dv = 32).  (512^2 / ch 16 / batch 1 measured once in
+    r03: D median 5.7e-2, G median 1.2e-1, projections 0.964 ... 1.02 - left out of the suite for its 5 minutes of
+    oracle time.)"""
     from oracle import ref_model as RM, ref_ops as R
     from tests.common import oracle_trainer, hip_model_like, dev_draws
     from tests.test_gpu_step import _kink_sync
@@ -570,9 +616,6 @@ def test_bf16_step_matches_the_bf16_rounded_oracle(img, ch, B, seed, tol, med_to
         def compare(tag, run_oracle, run_hip, loss_key):
             tr.vs.state_updates.clear()
             gan.store.load_arrays(hip0, reset_ema=False)
-            R.ROUND.on = False
-            plain = run_oracle()                                  # float64, no rounding: the diagnostic
-            tr.vs.state_updates.clear()
             R.ROUND.on = True
             try:
                 ro, ho, flips = _kink_sync(tr, run_oracle, run_hip, near=KINK_NEAR)
@@ -591,7 +634,6 @@ def test_bf16_step_matches_the_bf16_rounded_oracle(img, ch, B, seed, tol, med_to
                     continue
                 got = t2n(gan.store.vars[k].bg_grad).astype(np.float64)
                 errs[k] = rel_err(got, gr)
-                errs64[k] = rel_err(got, plain["grads"][k].numpy())
                 if gr.size >= 256:
                     proj[k] = float((got * gr).sum() / (gr * gr).sum())
             top = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
@@ -600,8 +642,6 @@ def test_bf16_step_matches_the_bf16_rounded_oracle(img, ch, B, seed, tol, med_to
             print("bf16 vs ROUNDED oracle [%s %d^2 ch%d B%d]: loss %.6f / %.6f, kink elements %d, gradient tensors: "
                   "median %.2e, worst %s; worst projection %s %.4f"
                   % (tag, img, ch, B, lh, lo, nflip, med, ", ".join("%s %.3f" % kv for kv in top), wp, proj[wp]))
-            print("   (diagnostic, vs float64 without rounding: median %.2e, worst %.3f)"
-                  % (float(np.median(list(errs64.values()))), max(errs64.values())))
             assert abs(lh - lo) <= 1e-2 * abs(lo), (tag, lh, lo)
             for k, p in proj.items():
                 assert abs(p - 1.0) <= (8e-2 if k.startswith("generator/first/") else 3e-2), (tag, "projection", k, p)
