@@ -1621,10 +1621,13 @@ static void plan_tn16(TN16Params& p) {
 
 // wide form (tn16x_kernel): used when there are at least two 128-row tiles of output and the reduction fills the ring;
 // split so that the grid is a whole number of rounds of 256 co-resident blocks (one per CU)
-// 256-wide output tiles (tn16x_kernel<.., 2>) where they divide the output channels: C = 768, 1536 (BG_TN16X_NBI=1: off)
+// 256-wide output tiles (tn16x_kernel<.., 2>) where they divide the output channels: C = 512, 768, 1536.  OFF by default:
+// measured r03 (config 3, same box): 102.7 ms / iteration with it, 102.9 without at batch 256, 25.6 / 25.6 at batch 32 -
+// the third fewer L2 -> LDS bytes and LDS operand reads buy nothing once only one block (2 waves per SIMD) fits a CU.
+// BG_TN16X_NBI=2 switches it on (tests/test_gpu_bf16.py keeps it exact).
 static int tn16x_nbi(const TN16Params& p) {
     const char* e = getenv("BG_TN16X_NBI");
-    if (e && atoi(e) == 1) return 1;
+    if (!e || atoi(e) != 2) return 1;
     return (p.Cb >= 512 && p.Cb % 256 == 0 && p.Mf >= 256) ? 2 : 1;
 }
 
