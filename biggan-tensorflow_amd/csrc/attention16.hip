@@ -154,12 +154,25 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const __bf16* __restric
     a16_load_row_regs<DQT>(q + b * gm.sq + (int64_t)(q0 + col) * gm.ldq, gm.d, half, qf);
     const __bf16* kb = k + b * gm.sk;
     const __bf16* vb = v + b * gm.sv;
-    A16Tile<16 * DQT> tk;
-    A16Tile<32 * DVT> tv;
-    tk.load(kb, gm.ldk, gm.d);
-    tv.load(vb, gm.ldv, gm.dv);
-    tk.store(Ks[0]);
-    tv.store(Vs[0]);
+    // Key / value tiles of 32 keys travel global -> registers -> LDS (double-buffered).  TWO tiles are kept in flight in
+    // registers (8 + 24 bytes per thread each): a tile's load is issued two iterations before its LDS store.  With one in
+    // flight (r02) an iteration - 8 MFMAs, ~0.2 us - could not cover the ~1.5 us of a global load, and the kernel ran
+    // at the load latency: 860 us for the generator's shape at batch 256 against ~110 us of MFMA time.
+    A16Tile<16 * DQT> tk0, tk1;
+    A16Tile<32 * DVT> tv0, tv1;
+    const int ntiles = gm.Nk / 32;
+    tk0.load(kb, gm.ldk, gm.d);
+    tv0.load(vb, gm.ldv, gm.dv);
+    tk0.store(Ks[0]);
+    tv0.store(Vs[0]);
+    if (ntiles > 1) {
+        tk1.load(kb + (int64_t)32 * gm.ldk, gm.ldk, gm.d);
+        tv1.load(vb + (int64_t)32 * gm.ldv, gm.ldv, gm.dv);
+    }
+    if (ntiles > 2) {
+        tk0.load(kb + (int64_t)64 * gm.ldk, gm.ldk, gm.d);
+        tv0.load(vb + (int64_t)64 * gm.ldv, gm.ldv, gm.dv);
+    }
     __syncthreads();
 
     int vtr[DVT][2];
@@ -174,13 +187,10 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const __bf16* __restric
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int ntiles = gm.Nk / 32;
-    for (int it = 0; it < ntiles; ++it) {
+    // one key tile: scores, online softmax, P V on LDS buffer `cur`; then tile it + 1 (registers nk / nv, loaded two
+    // iterations ago) goes into the other buffer and those registers take tile it + 3
+    auto tile = [&](int it, auto& nk, auto& nv) {
         const int cur = it & 1;
-        if (it + 1 < ntiles) {
-            tk.load(kb + (int64_t)(it + 1) * 32 * gm.ldk, gm.ldk, gm.d);
-            tv.load(vb + (int64_t)(it + 1) * 32 * gm.ldv, gm.ldv, gm.dv);
-        }
         a16_f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
@@ -214,10 +224,18 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const __bf16* __restric
             for (int t = 0; t < DVT; ++t) oacc[t] = A16_MFMA(a16_tr_frag(vcur, vtr[t], s), pb, oacc[t]);
         }
         if (it + 1 < ntiles) {
-            tk.store(Ks[cur ^ 1]);
-            tv.store(Vs[cur ^ 1]);
+            nk.store(Ks[cur ^ 1]);
+            nv.store(Vs[cur ^ 1]);
+        }
+        if (it + 3 < ntiles) {
+            nk.load(kb + (int64_t)(it + 3) * 32 * gm.ldk, gm.ldk, gm.d);
+            nv.load(vb + (int64_t)(it + 3) * 32 * gm.ldv, gm.ldv, gm.dv);
         }
         __syncthreads();
+    };
+    for (int it = 0; it < ntiles; it += 2) {
+        tile(it, tk1, tv1);                       // (tile it + 1 sits in the odd register set)
+        if (it + 1 < ntiles) tile(it + 1, tk0, tv0);
     }
     const float inv = 1.f / l_run;
     __bf16* ob = o + b * gm.so + (int64_t)(q0 + col) * gm.ldo;

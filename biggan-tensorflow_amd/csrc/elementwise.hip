@@ -1328,37 +1328,6 @@ struct PreluDalphaFnT {
     }
 };
 
-// PReLU backward in ONE pass (ops.py:532-537 under autodiff): dx = dy * prelu'(x) (+ add) is stored while the slope
-// gradient dalpha[c] += dy * min(x, 0) is reduced over rows - the stand-alone reduction read x and dy a second time
-template <class TX, class TY>
-struct PreluBwdFusedFnT {
-    const TX* x;
-    const TY* dy;
-    const float* alpha;
-    TX* dx;
-    const TX* add;
-    int C;
-    template <int VEC>
-    __device__ __forceinline__ void operator()(int, int64_t r, int c, float (&acc)[1][VEC]) const {
-        float xv[VEC], dv[VEC], al[VEC], out[VEC];
-        loadv<VEC>(x + r * C + c, xv);
-        loadv<VEC>(dy + r * C + c, dv);
-        loadv<VEC>(alpha + c, al);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            acc[0][j] += dv[j] * fminf(xv[j], 0.f);
-            out[j] = dv[j] * prelu_d(xv[j], al[j]);
-        }
-        if (add) {
-            float av[VEC];
-            loadv<VEC>(add + r * C + c, av);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) out[j] += av[j];
-        }
-        storev<VEC>(dx + r * C + c, out);
-    }
-};
-
 template <class T>
 struct BiasGradFnT {
     const T* dy;
@@ -2699,16 +2668,6 @@ int bg_prelu_bwd_t(const void* x, int x_dtype, const void* dy, int y_dtype, cons
     const bool x8 = x_dtype == BG_BF16 && y_dtype == BG_BF16 && C % 8 == 0 && rows < (int64_t(1) << 31) &&
                     ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0 &&
                     ((uintptr_t)dx_add & 15) == 0;
-    if (dx && dalpha && x_dtype == y_dtype && C % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 &&
-        ((uintptr_t)dx & 15) == 0 && ((uintptr_t)dx_add & 15) == 0) {
-        // both gradients in one pass over x and dy
-        BG_DISPATCH_XY(x_dtype, y_dtype,
-                       PreluBwdFusedFnT<TX, TY> fn{(const TX*)x, (const TY*)dy, alpha, (TX*)dx, (const TX*)dx_add, C};
-                       launch_colreduce<1, sizeof(TX) == 2 && sizeof(TY) == 2>(fn, dalpha, 0, rows, 1, C,
-                                                                               as_stream(stream)));
-        BG_LAUNCH_CHECK();
-        return BG_OK;
-    }
     if (dx && x8) {
         hipLaunchKernelGGL((prelu_bf16x8_kernel<true>), dim3(bn_x8_grid(rows, C / 8)), dim3(EW_BLOCK), 0, as_stream(stream),
                            (const __bf16*)x, (const __bf16*)dy, alpha, (__bf16*)dx, (const __bf16*)dx_add, (int)rows, C / 8);

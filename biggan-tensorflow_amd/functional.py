@@ -1208,19 +1208,6 @@ class PReluFn(Function):
         L = lib()
         dx = None
         f32s = x.dtype == torch.float32 and dy.dtype == torch.float32
-        want_da = ctx.needs_input_grad[1] and not _Mode.inputs_only
-        if (ctx.needs_input_grad[0] and want_da and not f32s and is_variable(alpha) and x.dtype == dy.dtype
-                and C % 4 == 0):
-            # dx and dalpha in ONE pass over x and dy (the slope gradient's own reduction read both a second time)
-            dx, add = _fork_target(ctx.fork, x)
-            slot, acc = grad_slot(alpha)
-            if not acc:
-                slot.zero_()
-            check(L.bg_prelu_bwd_t(act(x), dt(x), act(dy), dt(dy), f32(alpha), act(dx), f32(slot), act(dx) if add else None,
-                                   rows, C, stream()))
-            _fork_done(ctx.fork, dx)
-            ctx.x = None
-            return dx, None
         if ctx.needs_input_grad[0]:
             if f32s:
                 dx = torch.empty_like(x)
