@@ -129,6 +129,15 @@ __device__ __forceinline__ void a16_store4(__bf16* p, float a, float b, float c,
     *reinterpret_cast<uint2*>(p) = v;
 }
 
+// Barrier of the tile loops: this wave's LDS reads / writes are complete (lgkmcnt), then the block barrier - and NOTHING
+// about global memory.  __syncthreads() carries a workgroup fence, i.e. s_waitcnt vmcnt(0): it drained the register
+// prefetch of the next key / value tiles at every tile, so each iteration (8 - 20 MFMAs, ~0.2 us) waited out a full global
+// load (~1.5 us): 1.7 us per tile in all three kernels of round 2, whatever their arithmetic.
+__device__ __forceinline__ void a16_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 struct A16Geom {
     int N, Nk, d, dv;
     int64_t ldq, ldk, ldv, ldo;          // row strides (elements)
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const __bf16* __restric
             nk.load(kb + (int64_t)(it + 3) * 32 * gm.ldk, gm.ldk, gm.d);
             nv.load(vb + (int64_t)(it + 3) * 32 * gm.ldv, gm.ldv, gm.dv);
         }
-        __syncthreads();
+        a16_lds_barrier();
     };
     for (int it = 0; it < ntiles; it += 2) {
         tile(it, tk1, tv1);                       // (tile it + 1 sits in the odd register set)
@@ -295,12 +304,21 @@ __global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(const __bf16* __rest
     const float delta_q = delta[(int64_t)b * gm.N + q0 + col];
     const __bf16* kb = k + b * gm.sk;
     const __bf16* vb = v + b * gm.sv;
-    A16Tile<16 * DQT> tk;
-    A16Tile<32 * DVT> tv;
-    tk.load(kb, gm.ldk, gm.d);
-    tv.load(vb, gm.ldv, gm.dv);
-    tk.store(Ks[0]);
-    tv.store(Vs[0]);
+    A16Tile<16 * DQT> tk0, tk1;                 // two tiles in flight in registers (see attn16_fwd_kernel)
+    A16Tile<32 * DVT> tv0, tv1;
+    const int ntiles = gm.Nk / 32;
+    tk0.load(kb, gm.ldk, gm.d);
+    tv0.load(vb, gm.ldv, gm.dv);
+    tk0.store(Ks[0]);
+    tv0.store(Vs[0]);
+    if (ntiles > 1) {
+        tk1.load(kb + (int64_t)32 * gm.ldk, gm.ldk, gm.d);
+        tv1.load(vb + (int64_t)32 * gm.ldv, gm.ldv, gm.dv);
+    }
+    if (ntiles > 2) {
+        tk0.load(kb + (int64_t)64 * gm.ldk, gm.ldk, gm.d);
+        tv0.load(vb + (int64_t)64 * gm.ldv, gm.ldv, gm.dv);
+    }
     __syncthreads();
 
     int ktr[MT][2];
@@ -314,13 +332,8 @@ __global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(const __bf16* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[t][r] = 0.f;
 
-    const int ntiles = gm.Nk / 32;
-    for (int it = 0; it < ntiles; ++it) {
+    auto tile = [&](int it, auto& nk, auto& nv) {
         const int cur = it & 1;
-        if (it + 1 < ntiles) {
-            tk.load(kb + (int64_t)(it + 1) * 32 * gm.ldk, gm.ldk, gm.d);
-            tv.load(vb + (int64_t)(it + 1) * 32 * gm.ldv, gm.ldv, gm.dv);
-        }
         a16_f32x16 st, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -341,10 +354,18 @@ __global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(const __bf16* __rest
             for (int t = 0; t < MT; ++t) dqacc[t] = A16_MFMA(a16_tr_frag(kcur, ktr[t], s), dsb, dqacc[t]);
         }
         if (it + 1 < ntiles) {
-            tk.store(Ks[cur ^ 1]);
-            tv.store(Vs[cur ^ 1]);
+            nk.store(Ks[cur ^ 1]);
+            nv.store(Vs[cur ^ 1]);
         }
-        __syncthreads();
+        if (it + 3 < ntiles) {
+            nk.load(kb + (int64_t)(it + 3) * 32 * gm.ldk, gm.ldk, gm.d);
+            nv.load(vb + (int64_t)(it + 3) * 32 * gm.ldv, gm.ldv, gm.dv);
+        }
+        a16_lds_barrier();
+    };
+    for (int it = 0; it < ntiles; it += 2) {
+        tile(it, tk1, tv1);
+        if (it + 1 < ntiles) tile(it + 1, tk0, tv0);
     }
     __bf16* qo = dq + b * sdq + (int64_t)(q0 + col) * lddq;
 #pragma unroll
@@ -387,20 +408,38 @@ __global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(const __bf16* __res
     const __bf16* gb = dout + b * sg;
     const float* lb = lse + (int64_t)b * gm.N;
     const float* db = delta + (int64_t)b * gm.N;
-    A16Tile<16 * DQT> tq;
-    A16Tile<32 * DVT> tg;
-    tq.load(qb, gm.ldq, gm.d);
-    tg.load(gb, ldg, gm.dv);
-    float l_pf = 0.f, d_pf = 0.f;
+    // query / dO tiles (and their lse / delta rows): two tiles in flight in registers (see attn16_fwd_kernel)
+    A16Tile<16 * DQT> tq0, tq1;
+    A16Tile<32 * DVT> tg0, tg1;
+    float l0 = 0.f, d0 = 0.f, l1 = 0.f, d1 = 0.f;
+    const int ntiles = gm.N / 32;
+    tq0.load(qb, gm.ldq, gm.d);
+    tg0.load(gb, ldg, gm.dv);
     if (threadIdx.x < 32) {
-        l_pf = lb[threadIdx.x];
-        d_pf = db[threadIdx.x];
+        l0 = lb[threadIdx.x];
+        d0 = db[threadIdx.x];
     }
-    tq.store(Qs[0]);
-    tg.store(Gs[0]);
+    tq0.store(Qs[0]);
+    tg0.store(Gs[0]);
     if (threadIdx.x < 32) {
-        Ls[0][threadIdx.x] = l_pf;
-        Ds[0][threadIdx.x] = d_pf;
+        Ls[0][threadIdx.x] = l0;
+        Ds[0][threadIdx.x] = d0;
+    }
+    if (ntiles > 1) {
+        tq1.load(qb + (int64_t)32 * gm.ldq, gm.ldq, gm.d);
+        tg1.load(gb + (int64_t)32 * ldg, ldg, gm.dv);
+        if (threadIdx.x < 32) {
+            l1 = lb[32 + threadIdx.x];
+            d1 = db[32 + threadIdx.x];
+        }
+    }
+    if (ntiles > 2) {
+        tq0.load(qb + (int64_t)64 * gm.ldq, gm.ldq, gm.d);
+        tg0.load(gb + (int64_t)64 * ldg, ldg, gm.dv);
+        if (threadIdx.x < 32) {
+            l0 = lb[64 + threadIdx.x];
+            d0 = db[64 + threadIdx.x];
+        }
     }
     __syncthreads();
 
@@ -422,17 +461,8 @@ __global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(const __bf16* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) dkacc[t][r] = 0.f;
 
-    const int ntiles = gm.N / 32;
-    for (int it = 0; it < ntiles; ++it) {
+    auto tile = [&](int it, auto& nq, auto& ng, float& nl, float& nd) {
         const int cur = it & 1;
-        if (it + 1 < ntiles) {
-            tq.load(qb + (int64_t)(it + 1) * 32 * gm.ldq, gm.ldq, gm.d);
-            tg.load(gb + (int64_t)(it + 1) * 32 * ldg, ldg, gm.dv);
-            if (threadIdx.x < 32) {
-                l_pf = lb[(it + 1) * 32 + threadIdx.x];
-                d_pf = db[(it + 1) * 32 + threadIdx.x];
-            }
-        }
         a16_f32x16 st, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -463,14 +493,26 @@ __global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(const __bf16* __res
             for (int t = 0; t < MT; ++t) dkacc[t] = A16_MFMA(a16_tr_frag(qcur, qtr[t], s), dsb, dkacc[t]);
         }
         if (it + 1 < ntiles) {
-            tq.store(Qs[cur ^ 1]);
-            tg.store(Gs[cur ^ 1]);
+            nq.store(Qs[cur ^ 1]);
+            ng.store(Gs[cur ^ 1]);
             if (threadIdx.x < 32) {
-                Ls[cur ^ 1][threadIdx.x] = l_pf;
-                Ds[cur ^ 1][threadIdx.x] = d_pf;
+                Ls[cur ^ 1][threadIdx.x] = nl;
+                Ds[cur ^ 1][threadIdx.x] = nd;
             }
         }
-        __syncthreads();
+        if (it + 3 < ntiles) {
+            nq.load(qb + (int64_t)(it + 3) * 32 * gm.ldq, gm.ldq, gm.d);
+            ng.load(gb + (int64_t)(it + 3) * 32 * ldg, ldg, gm.dv);
+            if (threadIdx.x < 32) {
+                nl = lb[(it + 3) * 32 + threadIdx.x];
+                nd = db[(it + 3) * 32 + threadIdx.x];
+            }
+        }
+        a16_lds_barrier();
+    };
+    for (int it = 0; it < ntiles; it += 2) {
+        tile(it, tq1, tg1, l1, d1);
+        if (it + 1 < ntiles) tile(it + 1, tq0, tg0, l0, d0);
     }
     __bf16* ko = dk + b * sdk + (int64_t)(k0 + col) * lddk;
 #pragma unroll
