@@ -138,6 +138,8 @@ __device__ __forceinline__ void a16_lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+constexpr float A16_LOG2E = 1.4426950408889634f;
+
 struct A16Geom {
     int N, Nk, d, dv;
     int64_t ldq, ldk, ldv, ldo;          // row strides (elements)
@@ -205,26 +207,33 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const __bf16* __restric
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < DQT; ++s) st = A16_MFMA(a16_row_frag(Ks[cur], lane, 2 * s + half), qf[s], st);
-        // online softmax for query `col` (this lane holds 16 of the tile's 32 keys, the other half the rest)
+        // online softmax for query `col` (this lane holds 16 of the tile's 32 keys, the other half the rest), in base 2:
+        // 2^(log2e (s - m)) - one multiply per score folded into the exponent's argument (v_exp_f32 is 2^x)
         float mx = st[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
+        const float mneg = -m_new * A16_LOG2E;
         float rs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            st[r] = __expf(st[r] - m_new);
+            st[r] = __builtin_amdgcn_exp2f(fmaf(st[r], A16_LOG2E, mneg));
             rs += st[r];
         }
         rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
+        // the running maximum settles after a few tiles: the 16 DVT rescaling multiplies are skipped (wave-uniform branch)
+        // while no query of this wave raised its maximum
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * A16_LOG2E);
+            l_run *= alpha;
+#pragma unroll
+            for (int t = 0; t < DVT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        }
+        l_run += rs;
         m_run = m_new;
-#pragma unroll
-        for (int t = 0; t < DVT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
         const uint32_t vcur = vs_lds + cur * (VIMG * A16_IMG);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -304,21 +313,12 @@ __global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(const __bf16* __rest
     const float delta_q = delta[(int64_t)b * gm.N + q0 + col];
     const __bf16* kb = k + b * gm.sk;
     const __bf16* vb = v + b * gm.sv;
-    A16Tile<16 * DQT> tk0, tk1;                 // two tiles in flight in registers (see attn16_fwd_kernel)
-    A16Tile<32 * DVT> tv0, tv1;
-    const int ntiles = gm.Nk / 32;
-    tk0.load(kb, gm.ldk, gm.d);
-    tv0.load(vb, gm.ldv, gm.dv);
-    tk0.store(Ks[0]);
-    tv0.store(Vs[0]);
-    if (ntiles > 1) {
-        tk1.load(kb + (int64_t)32 * gm.ldk, gm.ldk, gm.d);
-        tv1.load(vb + (int64_t)32 * gm.ldv, gm.ldv, gm.dv);
-    }
-    if (ntiles > 2) {
-        tk0.load(kb + (int64_t)64 * gm.ldk, gm.ldk, gm.d);
-        tv0.load(vb + (int64_t)64 * gm.ldv, gm.ldv, gm.dv);
-    }
+    A16Tile<16 * DQT> tk;
+    A16Tile<32 * DVT> tv;
+    tk.load(kb, gm.ldk, gm.d);
+    tv.load(vb, gm.ldv, gm.dv);
+    tk.store(Ks[0]);
+    tv.store(Vs[0]);
     __syncthreads();
 
     int ktr[MT][2];
@@ -332,8 +332,13 @@ __global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(const __bf16* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[t][r] = 0.f;
 
-    auto tile = [&](int it, auto& nk, auto& nv) {
+    const int ntiles = gm.Nk / 32;
+    for (int it = 0; it < ntiles; ++it) {
         const int cur = it & 1;
+        if (it + 1 < ntiles) {
+            tk.load(kb + (int64_t)(it + 1) * 32 * gm.ldk, gm.ldk, gm.d);
+            tv.load(vb + (int64_t)(it + 1) * 32 * gm.ldv, gm.ldv, gm.dv);
+        }
         a16_f32x16 st, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -354,18 +359,10 @@ __global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(const __bf16* __rest
             for (int t = 0; t < MT; ++t) dqacc[t] = A16_MFMA(a16_tr_frag(kcur, ktr[t], s), dsb, dqacc[t]);
         }
         if (it + 1 < ntiles) {
-            nk.store(Ks[cur ^ 1]);
-            nv.store(Vs[cur ^ 1]);
+            tk.store(Ks[cur ^ 1]);
+            tv.store(Vs[cur ^ 1]);
         }
-        if (it + 3 < ntiles) {
-            nk.load(kb + (int64_t)(it + 3) * 32 * gm.ldk, gm.ldk, gm.d);
-            nv.load(vb + (int64_t)(it + 3) * 32 * gm.ldv, gm.ldv, gm.dv);
-        }
-        a16_lds_barrier();
-    };
-    for (int it = 0; it < ntiles; it += 2) {
-        tile(it, tk1, tv1);
-        if (it + 1 < ntiles) tile(it + 1, tk0, tv0);
+        __syncthreads();
     }
     __bf16* qo = dq + b * sdq + (int64_t)(q0 + col) * lddq;
 #pragma unroll
@@ -408,38 +405,20 @@ __global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(const __bf16* __res
     const __bf16* gb = dout + b * sg;
     const float* lb = lse + (int64_t)b * gm.N;
     const float* db = delta + (int64_t)b * gm.N;
-    // query / dO tiles (and their lse / delta rows): two tiles in flight in registers (see attn16_fwd_kernel)
-    A16Tile<16 * DQT> tq0, tq1;
-    A16Tile<32 * DVT> tg0, tg1;
-    float l0 = 0.f, d0 = 0.f, l1 = 0.f, d1 = 0.f;
-    const int ntiles = gm.N / 32;
-    tq0.load(qb, gm.ldq, gm.d);
-    tg0.load(gb, ldg, gm.dv);
+    A16Tile<16 * DQT> tq;
+    A16Tile<32 * DVT> tg;
+    tq.load(qb, gm.ldq, gm.d);
+    tg.load(gb, ldg, gm.dv);
+    float l_pf = 0.f, d_pf = 0.f;
     if (threadIdx.x < 32) {
-        l0 = lb[threadIdx.x];
-        d0 = db[threadIdx.x];
+        l_pf = lb[threadIdx.x];
+        d_pf = db[threadIdx.x];
     }
-    tq0.store(Qs[0]);
-    tg0.store(Gs[0]);
+    tq.store(Qs[0]);
+    tg.store(Gs[0]);
     if (threadIdx.x < 32) {
-        Ls[0][threadIdx.x] = l0;
-        Ds[0][threadIdx.x] = d0;
-    }
-    if (ntiles > 1) {
-        tq1.load(qb + (int64_t)32 * gm.ldq, gm.ldq, gm.d);
-        tg1.load(gb + (int64_t)32 * ldg, ldg, gm.dv);
-        if (threadIdx.x < 32) {
-            l1 = lb[32 + threadIdx.x];
-            d1 = db[32 + threadIdx.x];
-        }
-    }
-    if (ntiles > 2) {
-        tq0.load(qb + (int64_t)64 * gm.ldq, gm.ldq, gm.d);
-        tg0.load(gb + (int64_t)64 * ldg, ldg, gm.dv);
-        if (threadIdx.x < 32) {
-            l0 = lb[64 + threadIdx.x];
-            d0 = db[64 + threadIdx.x];
-        }
+        Ls[0][threadIdx.x] = l_pf;
+        Ds[0][threadIdx.x] = d_pf;
     }
     __syncthreads();
 
@@ -461,8 +440,17 @@ __global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(const __bf16* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) dkacc[t][r] = 0.f;
 
-    auto tile = [&](int it, auto& nq, auto& ng, float& nl, float& nd) {
+    const int ntiles = gm.N / 32;
+    for (int it = 0; it < ntiles; ++it) {
         const int cur = it & 1;
+        if (it + 1 < ntiles) {
+            tq.load(qb + (int64_t)(it + 1) * 32 * gm.ldq, gm.ldq, gm.d);
+            tg.load(gb + (int64_t)(it + 1) * 32 * ldg, ldg, gm.dv);
+            if (threadIdx.x < 32) {
+                l_pf = lb[(it + 1) * 32 + threadIdx.x];
+                d_pf = db[(it + 1) * 32 + threadIdx.x];
+            }
+        }
         a16_f32x16 st, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -493,26 +481,14 @@ __global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(const __bf16* __res
             for (int t = 0; t < MT; ++t) dkacc[t] = A16_MFMA(a16_tr_frag(qcur, qtr[t], s), dsb, dkacc[t]);
         }
         if (it + 1 < ntiles) {
-            nq.store(Qs[cur ^ 1]);
-            ng.store(Gs[cur ^ 1]);
+            tq.store(Qs[cur ^ 1]);
+            tg.store(Gs[cur ^ 1]);
             if (threadIdx.x < 32) {
-                Ls[cur ^ 1][threadIdx.x] = nl;
-                Ds[cur ^ 1][threadIdx.x] = nd;
+                Ls[cur ^ 1][threadIdx.x] = l_pf;
+                Ds[cur ^ 1][threadIdx.x] = d_pf;
             }
         }
-        if (it + 3 < ntiles) {
-            nq.load(qb + (int64_t)(it + 3) * 32 * gm.ldq, gm.ldq, gm.d);
-            ng.load(gb + (int64_t)(it + 3) * 32 * ldg, ldg, gm.dv);
-            if (threadIdx.x < 32) {
-                nl = lb[(it + 3) * 32 + threadIdx.x];
-                nd = db[(it + 3) * 32 + threadIdx.x];
-            }
-        }
-        a16_lds_barrier();
-    };
-    for (int it = 0; it < ntiles; it += 2) {
-        tile(it, tq1, tg1, l1, d1);
-        if (it + 1 < ntiles) tile(it + 1, tq0, tg0, l0, d0);
+        __syncthreads();
     }
     __bf16* ko = dk + b * sdk + (int64_t)(k0 + col) * lddk;
 #pragma unroll
