@@ -1805,7 +1805,9 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_batch_colsum_kernel(const BgSnIte
     }
 }
 
-__global__ __launch_bounds__(EW_BLOCK) void sn_batch_finalize_kernel(const BgSnItem* __restrict__ items, char* ws) {
+// write_v: also store v_hat (power-iteration-only calls: the normalisation that would store it runs elsewhere)
+__global__ __launch_bounds__(EW_BLOCK) void sn_batch_finalize_kernel(const BgSnItem* __restrict__ items, char* ws,
+                                                                      int write_v) {
     __shared__ float sh[4];
     const BgSnItem it = items[blockIdx.x];
     double* scr = sn_scr(it, ws);
@@ -1816,10 +1818,17 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_batch_finalize_kernel(const BgSnI
     if (threadIdx.x == 0) scr[0] = (double)ss;
     __syncthreads();
     sn_finalize_body(scr, scr + 4, it.u, it.sigma, it.cols, sh);
+    if (write_v) {
+        __syncthreads();
+        const float rs_v = (float)scr[2];
+        for (int r = threadIdx.x; r < it.rows; r += EW_BLOCK) it.v[r] = vraw[r] * rs_v;
+    }
 }
 
+// from_state: sigma is read from the item's sigma slot and v_hat is left alone - the power iteration ran elsewhere (on
+// the rank that owns the weight under data parallelism) and its results arrived by an all-gather of sigma | u | v_hat
 __global__ __launch_bounds__(EW_BLOCK) void sn_batch_normalize_kernel(const BgSnItem* __restrict__ items, int n_items,
-                                                                       char* ws) {
+                                                                       char* ws, int from_state) {
     __shared__ float tile[64][65];
     __shared__ int start[257];
     const int total = sn_sched_build(start, items, n_items, 2, nullptr);
@@ -1829,14 +1838,23 @@ __global__ __launch_bounds__(EW_BLOCK) void sn_batch_normalize_kernel(const BgSn
         const int bid = unit - start[j], nb = start[j + 1] - start[j];
         double* scr = sn_scr(it, ws);
         const float* vraw = reinterpret_cast<const float*>(scr + 4 + it.cols);
+        const float sigma = from_state ? *it.sigma : (float)scr[1];
         if (it.pack_p) {
             // conv / transposed-conv kernel of the bf16-resident path: w / sigma in fp32 plus the two bf16 packed copies
-            sn_normalize_pack_body(it.w, (float)scr[1], it.w_norm, reinterpret_cast<__bf16*>(it.pack_p),
+            sn_normalize_pack_body(it.w, sigma, it.w_norm, reinterpret_cast<__bf16*>(it.pack_p),
                                    reinterpret_cast<__bf16*>(it.pack_t), it.taps, it.rows / it.taps, it.cols,
                                    it.pack_p_ld > 0 ? it.pack_p_ld : it.cols, bid, nb, tile);
-            const float rs_v = (float)scr[2];
-            for (int64_t i = (int64_t)bid * EW_BLOCK + threadIdx.x; i < it.rows; i += (int64_t)nb * EW_BLOCK)
-                it.v[i] = vraw[i] * rs_v;
+            if (!from_state) {
+                const float rs_v = (float)scr[2];
+                for (int64_t i = (int64_t)bid * EW_BLOCK + threadIdx.x; i < it.rows; i += (int64_t)nb * EW_BLOCK)
+                    it.v[i] = vraw[i] * rs_v;
+            }
+            continue;
+        }
+        if (from_state) {
+            const int64_t n = (int64_t)it.rows * it.cols;
+            for (int64_t i = (int64_t)bid * EW_BLOCK + threadIdx.x; i < n; i += (int64_t)nb * EW_BLOCK)
+                it.w_norm[i] = it.w[i] / sigma;
             continue;
         }
         sn_normalize_body(it.w, scr, vraw, it.w_norm, it.v, (int64_t)it.rows * it.cols, it.rows, bid, nb);
@@ -2438,25 +2456,43 @@ static bool sn_masks(const uint64_t* m, int n, SnMask* out, bool dflt) {
     return true;
 }
 
-int bg_spectral_norm_batch_fwd(const BgSnItem* items_dev, int n_items, void* ws, size_t ws_bytes, void* stream) {
-    BG_REQUIRE(items_dev && n_items > 0 && ws && ws_bytes > 0, "bg_spectral_norm_batch_fwd: bad argument");
-    BG_REQUIRE(((uintptr_t)ws & 15) == 0, "bg_spectral_norm_batch_fwd: workspace must be 16-byte aligned");
+static int sn_batch_phases(const BgSnItem* items_dev, int n_items, void* ws, size_t ws_bytes, int phase, void* stream,
+                           const char* who) {
+    BG_REQUIRE(items_dev && n_items > 0 && ws && ws_bytes > 0, "%s: bad argument", who);
+    BG_REQUIRE(((uintptr_t)ws & 15) == 0, "%s: workspace must be 16-byte aligned", who);
+    BG_REQUIRE(n_items <= 256, "%s: 1..256 items per call", who);
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(ws, 0, ws_bytes, s) != hipSuccess) {
-        set_error("bg_spectral_norm_batch_fwd: memset failed");
-        return BG_ERR_LAUNCH;
-    }
     char* w8 = reinterpret_cast<char*>(ws);
-    BG_REQUIRE(n_items <= 256, "bg_spectral_norm_batch_fwd: 1..256 items per call");
-    hipLaunchKernelGGL(sn_batch_rowdot_kernel, dim3(SN_GRID), dim3(EW_BLOCK), 0, s, items_dev, n_items, w8);
-    BG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sn_batch_colsum_kernel, dim3(SN_GRID), dim3(EW_BLOCK), 0, s, items_dev, n_items, w8);
-    BG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sn_batch_finalize_kernel, dim3(n_items), dim3(EW_BLOCK), 0, s, items_dev, w8);
-    BG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sn_batch_normalize_kernel, dim3(SN_GRID), dim3(EW_BLOCK), 0, s, items_dev, n_items, w8);
-    BG_LAUNCH_CHECK();
+    if (phase != BG_SN_NORMALIZE) {
+        if (hipMemsetAsync(ws, 0, ws_bytes, s) != hipSuccess) {
+            set_error("%s: memset failed", who);
+            return BG_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(sn_batch_rowdot_kernel, dim3(SN_GRID), dim3(EW_BLOCK), 0, s, items_dev, n_items, w8);
+        BG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sn_batch_colsum_kernel, dim3(SN_GRID), dim3(EW_BLOCK), 0, s, items_dev, n_items, w8);
+        BG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sn_batch_finalize_kernel, dim3(n_items), dim3(EW_BLOCK), 0, s, items_dev, w8,
+                           phase == BG_SN_POWER ? 1 : 0);
+        BG_LAUNCH_CHECK();
+    }
+    if (phase != BG_SN_POWER) {
+        hipLaunchKernelGGL(sn_batch_normalize_kernel, dim3(SN_GRID), dim3(EW_BLOCK), 0, s, items_dev, n_items, w8,
+                           phase == BG_SN_NORMALIZE ? 1 : 0);
+        BG_LAUNCH_CHECK();
+    }
     return BG_OK;
+}
+
+int bg_spectral_norm_batch_fwd(const BgSnItem* items_dev, int n_items, void* ws, size_t ws_bytes, void* stream) {
+    return sn_batch_phases(items_dev, n_items, ws, ws_bytes, BG_SN_ALL, stream, "bg_spectral_norm_batch_fwd");
+}
+
+int bg_spectral_norm_batch_phase(const BgSnItem* items_dev, int n_items, void* ws, size_t ws_bytes, int phase,
+                                 void* stream) {
+    BG_REQUIRE(phase == BG_SN_ALL || phase == BG_SN_POWER || phase == BG_SN_NORMALIZE,
+               "bg_spectral_norm_batch_phase: phase %d", phase);
+    return sn_batch_phases(items_dev, n_items, ws, ws_bytes, phase, stream, "bg_spectral_norm_batch_phase");
 }
 
 int bg_spectral_norm_batch_bwd(const BgSnItem* items_dev, int n_items, const uint64_t* enable_mask,

@@ -1503,6 +1503,7 @@ static int launch_nn16h_inst(const NN16Params& p, int blocks, hipStream_t s) {
 template <int NT, int MODE>
 static int launch_nn16h_nf(const NN16Params& p, int nf, int blocks, hipStream_t s) {
     switch (nf) {
+        case 1: return launch_nn16h_inst<NT, 1, MODE>(p, blocks, s);
         case 2: return launch_nn16h_inst<NT, 2, MODE>(p, blocks, s);
         case 3: return launch_nn16h_inst<NT, 3, MODE>(p, blocks, s);
         default: return launch_nn16h_inst<NT, 4, MODE>(p, blocks, s);
@@ -1529,7 +1530,9 @@ static int nn16_mfast(const NN16Params& p, int tiles_m, int tiles_n) {
 
 static int launch_nn16h(NN16Params& p, int mode, int ntaps, hipStream_t s) {
     int nf = 4, best = 1 << 30;
-    for (int c = 4; c >= 2; --c) {                      // least padded output channels; ties: the wider tile
+    // (c = 1, a 32-column tile, r03: the generator's 96 -> 3 (8) image layer - a quarter of the padded MFMA work of the
+    //  64-column tile and the input read once instead of once per tap by the tap kernel)
+    for (int c = 4; c >= 1; --c) {                      // least padded output channels; ties: the wider tile
         const int padded = (p.N + 32 * c - 1) / (32 * c) * (32 * c);
         if (padded < best) { best = padded; nf = c; }
     }

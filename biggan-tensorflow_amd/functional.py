@@ -262,6 +262,18 @@ class ZeroPool:
 
 
 _pool = None
+_run_stamp = [object()]
+
+
+def new_run_stamp():
+    """A fresh identity for the run that begins (ops.begin_run)."""
+    _run_stamp[0] = object()
+    return _run_stamp[0]
+
+
+def current_run_stamp():
+    return _run_stamp[0]
+
 
 
 def set_zero_pool(pool):
@@ -919,10 +931,17 @@ class SnBatch:
 
     ALIGN = 64
 
-    def __init__(self, pairs, groups=None):
+    def __init__(self, pairs, groups=None, shard=None):
         """``groups`` (bf16-resident mode): lists of indices into ``pairs`` of 1x1 kernels [1,1,C,c_i] applied to the
         same tensor (the f | g | h projections of self_attention_2): their packed copies are slices of one shared
-        [C, sum c_i] / [sum c_i, C] pair, so the three projections are ONE GEMM in each direction."""
+        [C, sum c_i] / [sum c_i, C] pair, so the three projections are ONE GEMM in each direction.
+
+        ``shard`` = (rank, world, process group) under data parallelism: the batch-independent power iteration (two
+        GEMV passes over every weight) is SHARDED by weight - each rank iterates the weights it owns
+        (longest-processing-time assignment by size) and an all-gather of sigma | u | v_hat brings everybody's results
+        to everybody; only the normalisation (which every rank needs for its packed copies) runs on all weights.  The
+        u vectors then live in one flat state buffer: ``self.u`` are views into it, and the caller re-points the store's
+        ``u`` variables to them."""
         import ctypes
         L = lib()
         self.w = [p[0] for p in pairs]
@@ -966,6 +985,39 @@ class SnBatch:
                 o += self.w[i].shape[3]
         self.v_flat = torch.zeros(rows_tot, dtype=torch.float32, device=dev)
         self.sigma = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.shard = shard
+        state_views = None
+        if shard is not None:
+            rank, world, _ = shard
+            pad4 = lambda k: (k + 3) // 4 * 4                                  # noqa: E731
+            load = [0] * world
+            self.owner = [0] * n
+            for i in sorted(range(n), key=lambda i: (-self.w[i].numel(), i)):
+                r = min(range(world), key=lambda q: (load[q], q))
+                self.owner[i] = r
+                load[r] += self.w[i].numel()
+            fill = [0] * world
+            place = []
+            for i in range(n):
+                r = self.owner[i]
+                o = fill[r]
+                place.append((r, o, o + 4, o + 4 + pad4(self.cols[i])))       # sigma | u | v_hat of item i inside r's segment
+                fill[r] = o + 4 + pad4(self.cols[i]) + pad4(self.rows[i])
+            self.seg = max(max(fill), 4)
+            self.state_flat = torch.zeros(world * self.seg, dtype=torch.float32, device=dev)
+            state_views = []
+            for i, (r, o_s, o_u, o_v) in enumerate(place):
+                base = r * self.seg
+                sg = self.state_flat.narrow(0, base + o_s, 1)
+                uu = self.state_flat.narrow(0, base + o_u, self.cols[i]).view(self.u[i].shape)
+                vv = self.state_flat.narrow(0, base + o_v, self.rows[i])
+                with torch.no_grad():
+                    uu.copy_(self.u[i])
+                for attr in ("bg_name", "bg_grad", "bg_touched"):
+                    if hasattr(self.u[i], attr):
+                        setattr(uu, attr, getattr(self.u[i], attr))
+                self.u[i] = uu
+                state_views.append((sg, vv))
         self.ws_bytes = ws_off
         self.ws = workspace(max(ws_off, 8 * n), dev)
         self.dots = workspace(8 * n, dev)
@@ -977,9 +1029,9 @@ class SnBatch:
             wn.bg_name = (getattr(w, "bg_name", None) or "w%d" % i) + ":sn"
             wn.bg_grad = self.gwn_flat.narrow(0, offs[i], w.numel()).view(w.shape)
             wn.bg_touched = False
-            wn.bg_sigma = self.sigma.narrow(0, i, 1)
+            wn.bg_sigma = self.sigma.narrow(0, i, 1) if state_views is None else state_views[i][0]
             w.bg_sn_wn = wn                     # (the regulariser of w finds the packed copy of w / sigma through this)
-            v = self.v_flat.narrow(0, r0, self.rows[i])
+            v = self.v_flat.narrow(0, r0, self.rows[i]) if state_views is None else state_views[i][1]
             r0 += (self.rows[i] + 3) // 4 * 4
             dw = getattr(w, "bg_grad", None)
             if dw is None:
@@ -991,7 +1043,7 @@ class SnBatch:
             self.dw.append(dw)
             it = items[i]
             it.w, it.u, it.v = w.data_ptr(), self.u[i].data_ptr(), v.data_ptr()
-            it.sigma = self.sigma.data_ptr() + 4 * i
+            it.sigma = wn.bg_sigma.data_ptr()
             it.w_norm, it.g_wnorm, it.dw = wn.data_ptr(), wn.bg_grad.data_ptr(), dw.data_ptr()
             it.ws_offset, it.rows, it.cols = ws_offs[i], self.rows[i], self.cols[i]
             if i in group_of:
@@ -1012,13 +1064,47 @@ class SnBatch:
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.n = n
         self._ctypes = ctypes
+        self.n_own = 0
+        if shard is not None:
+            own = [i for i in range(n) if self.owner[i] == shard[0]]
+            self.n_own = len(own)
+            if own:
+                sub = (hip.BgSnItem * len(own))(*[items[i] for i in own])
+                self.table_own = torch.frombuffer(bytearray(bytes(sub)), dtype=torch.uint8).to(dev)
 
-    def forward(self):
-        check(lib().bg_spectral_norm_batch_fwd(hip.ptr(self.table), self.n, hip.ptr(self.ws), self.ws_bytes, stream()))
+    def forward(self, run_stamp=None):
+        """``run_stamp``: identity of the run (ops.begin_run) in which the packed copies / sigma are written; consumers
+        that read them outside the conv path (the regulariser's Gram from the packed weights) check it, so that packs of an
+        earlier run - older weights, older sigma - are never used silently."""
+        if self.shard is None:
+            check(lib().bg_spectral_norm_batch_fwd(hip.ptr(self.table), self.n, hip.ptr(self.ws), self.ws_bytes, stream()))
+        else:
+            self.power_owned()
+            self.gather_state()
+            self.normalize_all()
         for w, wn in zip(self.w, self.wn):
             wn.requires_grad_(bool(w.requires_grad))
             wn.bg_touched = False
+            wn.bg_run_stamp = run_stamp
         return self.wn
+
+    def power_owned(self):
+        """Sharded mode, step 1: the power iteration (u, v_hat, sigma) of the weights this rank owns."""
+        if self.n_own:
+            check(lib().bg_spectral_norm_batch_phase(hip.ptr(self.table_own), self.n_own, hip.ptr(self.ws), self.ws_bytes,
+                                                     hip.SN_POWER, stream()))
+
+    def gather_state(self):
+        """Sharded mode, step 2: everybody's sigma | u | v_hat segment to everybody (one all-gather, in place)."""
+        rank, world, pg = self.shard
+        if world > 1:
+            torch.distributed.all_gather_into_tensor(self.state_flat, self.state_flat.narrow(0, rank * self.seg, self.seg),
+                                                     group=pg)
+
+    def normalize_all(self):
+        """Sharded mode, step 3: w / sigma (and the packed copies) of EVERY weight from the gathered sigma."""
+        check(lib().bg_spectral_norm_batch_phase(hip.ptr(self.table), self.n, hip.ptr(self.ws), self.ws_bytes,
+                                                 hip.SN_NORMALIZE, stream()))
 
     def backward(self):
         """dL/dw (+)= SN-backward of every normalised weight that received a gradient this step."""
@@ -1902,6 +1988,8 @@ class OrthoCosineRegFn(Function):
         A = torch.empty((c, c), dtype=torch.float32, device=dev)
         wn = getattr(w, "bg_sn_wn", None)
         pk = getattr(wn, "bg_pack_p", None) if wn is not None else None
+        if pk is not None and getattr(wn, "bg_run_stamp", None) is not current_run_stamp():
+            pk = None              # packs / sigma of an earlier run (no spectral-norm prefetch in this one): fp32 Gram instead
         if (Precision.resident and pk is not None and kind == "ortho_cosine" and c % 8 == 0
                 and os.environ.get("BG_REG_GRAM", "") != "fp32"):              # (BG_REG_GRAM=fp32: A/B switch)
             # bf16-resident mode: W^T W = sigma^2 (W/sigma)^T (W/sigma) from the packed bf16 copy of this run's spectral

@@ -19,6 +19,7 @@ PAD_REFLECT, PAD_ZERO = 0, 1
 PAD_ZERO_FILL, PAD_SPLIT, PAD_DUP, PAD_FOLD = 0, 1, 2, 3      # bg_pad_channels modes
 F32, BF16 = 0, 1                       # BG_F32 / BG_BF16: element types of activation tensors
 COMPUTE_F32, COMPUTE_BF16 = 0, 1       # per-call arithmetic of the GEMM-shaped launches
+SN_ALL, SN_POWER, SN_NORMALIZE = 0, 1, 2      # bg_spectral_norm_batch_phase
 
 
 class BgConvDesc(Structure):
@@ -98,6 +99,7 @@ SIGNATURES = {
     "bg_spectral_norm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
     "bg_spectral_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
     "bg_spectral_norm_batch_fwd": (c_int, [_P, c_int, _P, c_size_t, _P]),
+    "bg_spectral_norm_batch_phase": (c_int, [_P, c_int, _P, c_size_t, c_int, _P]),
     "bg_spectral_norm_batch_bwd": (c_int, [_P, c_int, _P, _P, _P, c_size_t, _P]),
     "bg_bn_stats": (c_int, [_P, _P, c_int64, c_int, _P]),
     "bg_bn_finalize": (c_int, [_P, c_double, c_float, c_float, c_int, _P, _P, _P, _P, c_int, _P]),

@@ -436,7 +436,17 @@ class BigGAN(GANBase):
                                 groups.append([j, chunk.index(pre + "g_conv/kernel"), chunk.index(pre + "h_conv/kernel")])
                             except ValueError:
                                 pass
-                    self.sn_batches.setdefault(group, []).append(Fn.SnBatch(pairs[i:i + 256], groups))
+                    # data parallelism: the power iteration is sharded by weight (SnBatch docstring; BG_SHARD_SN=0: replicated)
+                    shard = None
+                    if (self.world > 1 or os.environ.get("BG_SHARD_OPT", "") == "force") \
+                            and os.environ.get("BG_SHARD_SN", "1") != "0" \
+                            and torch.distributed.is_available() and torch.distributed.is_initialized():
+                        shard = (self.rank, self.world, self.pg)
+                    sb = Fn.SnBatch(pairs[i:i + 256], groups, shard)
+                    if shard is not None:          # the u vectors now live in the batch's flat state buffer
+                        for j, nm in enumerate(chunk):
+                            self.store.vars[self.store.sn_pairs[nm]] = sb.u[j]
+                    self.sn_batches.setdefault(group, []).append(sb)
         self.reg_owner = self._shard_regularisers()
         self._setup_exchange()
         self.counter = 0

@@ -46,6 +46,7 @@ def begin_run(reduce_fn=None, world=1, rank=0, reg_owner=None, zero_pool=None):
     (functional.ZeroPool) serves the run's zero-initialised accumulators from one buffer cleared by one fill."""
     _run.sn_cache = {}
     _run.dense_cache = {}
+    Fn.new_run_stamp()
     Fn.set_zero_pool(zero_pool)
     if zero_pool is not None:
         zero_pool.begin_run()
@@ -65,7 +66,7 @@ def sn_prefetch(batch):
         return                  # a second instantiation of the network in the same run reuses the first
     _run.sn_prefetched.add(id(batch))
     needs_base = torch.is_grad_enabled()
-    for w, wn in zip(batch.w, batch.forward()):
+    for w, wn in zip(batch.w, batch.forward(Fn.current_run_stamp())):
         _run.sn_cache[w.bg_name] = (wn, needs_base and w.requires_grad)
 
 

@@ -248,6 +248,18 @@ typedef struct BgSnItem {
                             * their pack_t copies are row blocks of a common [sum cols][rows] matrix (plain offsets) */
 } BgSnItem;
 int bg_spectral_norm_batch_fwd(const BgSnItem* items_dev, int n_items, void* ws, size_t ws_bytes, void* stream);
+/* The same in two halves, for data parallelism (last row: the batch-independent power iteration is
+ * SHARDED by weight instead of repeated on every rank):
+ *   BG_SN_POWER      the two GEMV passes + finalisation of the items given (a rank's OWN weights: a sub-table): writes
+ *                    u (in place), sigma and v_hat of those items - nothing else
+ *   BG_SN_NORMALIZE  w / sigma (+ packed bf16 copies) of the items given (ALL weights), sigma read from each item's
+ *                    sigma slot - filled for the other ranks' weights by an all-gather of sigma | u | v_hat in between
+ *   BG_SN_ALL        both, = bg_spectral_norm_batch_fwd */
+#define BG_SN_ALL 0
+#define BG_SN_POWER 1
+#define BG_SN_NORMALIZE 2
+int bg_spectral_norm_batch_phase(const BgSnItem* items_dev, int n_items, void* ws, size_t ws_bytes, int phase,
+                                 void* stream);
 int bg_spectral_norm_batch_bwd(const BgSnItem* items_dev, int n_items, const uint64_t* enable_mask,
                                const uint64_t* accumulate_mask, void* ws, size_t ws_bytes, void* stream);
 

@@ -374,6 +374,34 @@ def test_spectral_norm_fwd_bwd(shape):
     assert rel_err(t2n(wc.grad).reshape(-1, cols), exp.numpy()) < 5e-5
 
 
+def test_spectral_norm_batch_sharded_by_weight_matches_the_replicated_batch():
+    """SnBatch(shard=...): two owners iterate their own weights, exchange their sigma | u | v_hat segments (what the
+    all-gather does, done by hand here) and normalise everything - same w / sigma, u, v_hat, sigma as one batch."""
+    Fn = _fn()
+    shapes = [(3, 3, 16, 32), (32, 64), (4, 4, 8, 24), (184, 1024), (3, 3, 8, 3), (16, 1), (1, 1, 64, 8), (20, 2050)]
+    rng = np.random.default_rng(78)
+    ws = [rng.standard_normal(s) * 0.1 for s in shapes]
+    us = [rng.standard_normal((1, s[-1])) for s in shapes]
+    plain = Fn.SnBatch([(cu(w, True), cu(u)) for w, u in zip(ws, us)])
+    ref = plain.forward()
+    ranks = [Fn.SnBatch([(cu(w, True), cu(u)) for w, u in zip(ws, us)], None, (r, 2, None)) for r in (0, 1)]
+    assert ranks[0].owner == ranks[1].owner and set(ranks[0].owner) == {0, 1}
+    assert ranks[0].n_own + ranks[1].n_own == len(shapes)
+    for sb in ranks:
+        sb.power_owned()
+    seg = ranks[0].seg
+    for r in (0, 1):                                       # rank r's segment to the other rank
+        ranks[1 - r].state_flat[r * seg:(r + 1) * seg].copy_(ranks[r].state_flat[r * seg:(r + 1) * seg])
+    for sb in ranks:
+        sb.normalize_all()
+        for i in range(len(shapes)):
+            assert rel_err(t2n(sb.wn[i]), t2n(ref[i])) < 1e-6, shapes[i]
+            assert rel_err(t2n(sb.u[i]), t2n(plain.u[i])) < 1e-6, shapes[i]
+            assert rel_err(t2n(sb.v[i]), t2n(plain.v[i])) < 1e-6, shapes[i]
+            assert abs(sb.wn[i].bg_sigma.item() - plain.sigma[i].item()) < 1e-6 * abs(plain.sigma[i].item())
+    assert torch.equal(ranks[0].state_flat, ranks[1].state_flat)
+
+
 def test_spectral_norm_multi_tensor_batch():
     """functional.SnBatch: all weights of a network in one call; bwd with skip / overwrite / accumulate."""
     Fn = _fn()

@@ -724,9 +724,12 @@ def test_hip_graph_replay_matches_eager_iterations():
         lr = gan.g_learning_rate if k.startswith("generator") else gan.d_learning_rate
         diff = (snap[k] - eager_state[k]).abs()
         assert float(diff.max()) <= 2.0 * 3 * lr * 1.01, (k, float(diff.max()))
+        # ... and those elements are FEW: a zero-initialised bias is +-lr-sized after three steps, so one flipped sign in
+        # a 2048-element bias is already 2e-2 of its norm (seen on generator/first/dense2/bias when the suite's allocator
+        # history changed the order of the atomically accumulated sums) - count elements instead of norms
         if eager_state[k].numel() >= 64 and not _noise_driven(k):
-            rel = float(diff.double().norm() / eager_state[k].double().norm().clamp_min(1e-30))
-            assert rel < 5e-3, (k, rel)
+            moved = int((diff > 0.1 * lr).sum())
+            assert moved <= 2 + 0.005 * diff.numel(), (k, moved, diff.numel())
     for k in snap:
         if k.endswith("/u"):
             floor = float((eager_again[k] - eager_state[k]).abs().max())
