@@ -1136,7 +1136,10 @@ int bg_conv2d_dgrad(const BgConvDesc* d, const void* dy, const void* w, const fl
         if (!padded) {
             r.out = dx; r.accumulate = accumulate;
             const NN16Params plain = r;
-            rc = launch_nn16(r, GATHER_TCONV, d->stride * d->stride, out_elems, ws, ws_bytes, as_stream(stream));
+            if (nn16h_d2s_ok(plain))            // 8-channel image layers, stride 2: one 2 x 2-window launch (igemm16.hip)
+                rc = launch_nn16h_d2s(plain, as_stream(stream));
+            else
+                rc = launch_nn16(r, GATHER_TCONV, d->stride * d->stride, out_elems, ws, ws_bytes, as_stream(stream));
             if (rc || !ring) return rc;
             NN16Params q = plain;
             q.ring = 1;

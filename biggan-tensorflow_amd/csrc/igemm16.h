@@ -69,6 +69,8 @@ int64_t nn16_stats_rows(const NN16Params& p, int mode, int zdim);
 // the mirrored-tap launch of a reflect-padded convolution's input gradient (p.ring = 1, p.ring_lines, p.g of the plain
 // launch, accumulate = 1): see NN16Params::ring
 int launch_nn16_ring(NN16Params& p, hipStream_t s);
+bool nn16h_d2s_ok(const NN16Params& p);                    // 8-channel stride-2 input gradients: depth-to-space halo form
+int launch_nn16h_d2s(const NN16Params& plain, hipStream_t s);
 size_t tn16_workspace_bytes(const TN16Params& p);
 int launch_tn16(TN16Params& p, int mode, float* final_out, void* ws, size_t ws_bytes, hipStream_t s);
 // dx[b,h,w,:] (+)= sum of the padded-grid gradient dxp[b,i,j,:] over the padded positions (i,j) that tf.pad(REFLECT)

@@ -420,14 +420,16 @@ def test_position_major_rows_match_the_image_major_walk(kind, N, H, Cin, Cout, k
                                                  (1, 32, 32, 8, 1, torch.bfloat16), (70, 8, 16, 16, 2, torch.bfloat16),
                                                  (2, 16, 16, 24, 2, torch.bfloat16), (1, 64, 8, 8, 2, torch.bfloat16),
                                                  (2, 16, 3, 16, 2, torch.float32), (2, 12, 3, 8, 1, torch.float32),
-                                                 (2, 6, 8, 8, 1, torch.bfloat16), (1, 10, 8, 16, 2, torch.bfloat16)])
+                                                 (2, 6, 8, 8, 1, torch.bfloat16), (1, 10, 8, 16, 2, torch.bfloat16),
+                                                 (2, 64, 8, 32, 2, torch.bfloat16), (3, 32, 8, 96, 2, torch.bfloat16)])
 def test_reflect_conv_input_gradient_without_the_padded_grid(N, H, Cin, Cout, s, xdt):
     """Input gradient of tf.pad(REFLECT) + VALID conv (ops.py:81-82, 94): the plain transposed gather on the H x W map
     plus the two mirrored-tap launches (igemm16.hip NN16Params::ring) against the float64 gradient, EXACTLY - the operands
     are small integers, so every product and sum is exact in bf16 / fp32 and any missing, doubled or misplaced mirrored
     tap shows - and against round 2's padded-grid + fold form (BG_DGRAD_RING=0).  4 x 4 ... 64 x 64 maps, both strides,
     non-power-of-two maps, batches that put one, two or many positions into a 128-row tile, the fp32 image gradient of
-    the discriminator's first layer."""
+    the discriminator's first layer; the last two shapes (8 input channels, stride 2, maps of 32 / 16 source pixels) take
+    the depth-to-space halo form for the plain part (nn16h_kernel THIN = 1)."""
     from biggan_tensorflow_amd import functional as Fn, hip
     Fn.set_precision("bf16")
     try:
@@ -456,6 +458,44 @@ def test_reflect_conv_input_gradient_without_the_padded_grid(N, H, Cin, Cout, s,
     finally:
         os.environ.pop("BG_DGRAD_RING", None)
         Fn.set_precision("fp32")
+
+
+@pytest.mark.parametrize("pad_mode,acc,xdt", [("zero", False, torch.bfloat16), ("zero", True, torch.float32),
+                                              ("reflect", True, torch.bfloat16), ("reflect", False, torch.float32)])
+def test_image_layer_input_gradient_depth_to_space_form(pad_mode, acc, xdt):
+    """bg_conv2d_dgrad of a 3 x 3 stride-2 pad-1 convolution with 8 input channels (the discriminator's image layers,
+    ops.py:94): the depth-to-space halo form (one launch, the four output parities as 4 x 8 columns) against the generic
+    stride-phase launches (BG_THIN_D2S=0), exactly on small-integer operands - zero and reflect padding, with and without
+    accumulation into an existing gradient, bf16 and fp32 (the image gradient's type) outputs."""
+    import ctypes
+    from biggan_tensorflow_amd import functional as Fn, hip
+    N, H, Cout = 2, 64, 96
+    rng = np.random.default_rng(5)
+    w = torch.tensor(rng.integers(-1, 2, size=(3, 3, 8, Cout)), dtype=torch.float32, device="cuda")
+    dy = torch.tensor(rng.integers(-1, 2, size=(N, H // 2, H // 2, Cout)) * (rng.random((N, H // 2, H // 2, Cout)) < 0.2),
+                      dtype=torch.bfloat16, device="cuda")
+    prior = torch.tensor(rng.integers(-3, 4, size=(N, H, H, 8)), dtype=xdt, device="cuda")
+    L = hip.lib()
+    d = hip.conv_desc(N, H, H, 8, H // 2, H // 2, Cout, 3, 2, 1,
+                      hip.PAD_REFLECT if pad_mode == "reflect" else hip.PAD_ZERO, compute=hip.COMPUTE_BF16,
+                      x_dtype=hip.BF16 if xdt == torch.bfloat16 else hip.F32, y_dtype=hip.BF16, w_packed=1)
+    wp = Fn.weight_packs(w)[0]
+    out = {}
+    try:
+        for form in ("1", "0"):
+            os.environ["BG_THIN_D2S"] = form
+            os.environ["BG_DGRAD_RING"] = "1"
+            dx = prior.clone() if acc else torch.full_like(prior, 7.0)
+            nb = L.bg_conv2d_dgrad_workspace_bytes(ctypes.byref(d))
+            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+            hip.check(L.bg_conv2d_dgrad(ctypes.byref(d), hip.ptr(dy), hip.ptr(wp), None, hip.ptr(dx), int(acc), hip.ptr(ws), nb,
+                                        Fn.stream()))
+            out[form] = dx.float().cpu().numpy()
+    finally:
+        os.environ.pop("BG_THIN_D2S", None)
+        os.environ.pop("BG_DGRAD_RING", None)
+    assert np.abs(out["0"]).max() > 0
+    assert np.array_equal(out["1"], out["0"]), np.argwhere(out["1"] != out["0"])[:8].tolist()
 
 
 @pytest.mark.parametrize("N,H,Cin,Cout,k,s,acc", [(3, 16, 64, 96, 4, 2, False), (2, 32, 96, 96, 3, 1, True),
