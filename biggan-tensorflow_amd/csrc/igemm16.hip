@@ -637,6 +637,14 @@ __global__ __launch_bounds__(512, 4) void nn16h_kernel(const NN16Params p) {    
     } else {
         base_h = base_w = g.pad - (NT - 1);
     }
+    // taps this block walks: all NT x NT, except in the stride phases of a kernel with k < NT * stride (3 x 3 stride 2, r03:
+    // 1 / 2 / 2 / 4 taps) - there only the window rows / columns hy >= NT - nkh (hx >= NT - nkw) carry a tap
+    int nkh = NT, nkw = NT;
+    if (MODE == GATHER_TCONV && NT == 2 && g.pstep > 1) {
+        nkh = (g.k - kh0 + kstep - 1) / kstep;
+        nkw = (g.k - kw0 + kstep - 1) / kstep;
+    }
+    const int ntaps = (MODE == GATHER_TCONV && NT == 2) ? nkh * nkw : NTAPS;
 
     const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.A);
     const unsigned char* bbase = reinterpret_cast<const unsigned char*>(p.B);
@@ -691,8 +699,9 @@ __global__ __launch_bounds__(512, 4) void nn16h_kernel(const NN16Params p) {    
         }
     };
     auto issue_w = [&](int step) {                      // weight tile [BN][64 channels] of (chunk, tap)
-        const int chunk = step / NTAPS, tap = step - chunk * NTAPS;
-        const int hy = tap / NT, hx = tap - hy * NT;
+        const int chunk = step / ntaps, tap = step - chunk * ntaps;
+        const int ty_ = tap / nkw;
+        const int hy = NT - nkh + ty_, hx = NT - nkw + (tap - ty_ * nkw);
         const int kh = MODE == GATHER_CONV ? hy : kh0 + kstep * (NT - 1 - hy);
         const int kw = MODE == GATHER_CONV ? hx : kw0 + kstep * (NT - 1 - hx);
         const int64_t toff = 2 * ((int64_t)(kh * g.k + kw) * p.tap_stride);
@@ -732,17 +741,17 @@ __global__ __launch_bounds__(512, 4) void nn16h_kernel(const NN16Params p) {    
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
     const int nchunks = (p.C + 63) >> 6;
-    const int T = nchunks * NTAPS;
+    const int T = nchunks * ntaps;
     issue_a(0);
     issue_w(0);
 
     for (int step = 0; step < T; ++step) {
-        const int chunk = step / NTAPS, tap = step - chunk * NTAPS;
+        const int chunk = step / ntaps, tap = step - chunk * ntaps;
         // W(step) (and at a chunk's first tap its halo tile, issued in front of it) has landed: nothing else is in flight
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (step + 1 < T) {
-            if (tap == NTAPS - 1) {
+            if (tap == ntaps - 1) {
                 // the next step starts a chunk: its halo tile goes into the ONE buffer this step still reads - so this
                 // step computes first (below) and issues after a barrier of its own
             } else {
@@ -750,7 +759,8 @@ __global__ __launch_bounds__(512, 4) void nn16h_kernel(const NN16Params p) {    
             }
         }
 
-        const int hy = tap / NT, hx = tap - hy * NT;
+        const int ty_ = tap / nkw;
+        const int hy = NT - nkh + ty_, hx = NT - nkw + (tap - ty_ * nkw);
         const uint32_t abuf = 0;
         const uint32_t wslot = (uint32_t)(step % NH_WS) * W_BYTES;
         const int tq = hy * WW + hx;
@@ -778,7 +788,7 @@ __global__ __launch_bounds__(512, 4) void nn16h_kernel(const NN16Params p) {    
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], a[i], acc[i][j], 0, 0, 0);
             }
         }
-        if (tap == NTAPS - 1 && step + 1 < T) {
+        if (tap == ntaps - 1 && step + 1 < T) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every wave has read the halo tile of this chunk
             __builtin_amdgcn_s_barrier();
             issue_a(chunk + 1);
@@ -1503,6 +1513,15 @@ static int nn16h_taps(const NN16Params& p, int mode, int zdim) {
     if (g.reflect) return 0;
     if (g.stride == 1 && g.k == 3 && g.pstep == 1 && zdim == 1) return 3;
     if (g.stride == 2 && g.k == 4 && g.pstep == 2 && zdim == 4) return 2;
+    // r03: the stride phases of a 3 x 3 stride-2 transposed gather (input gradients of the discriminator's down-sampling
+    // convolutions): windows of 1 x 1, 1 x 2, 2 x 1 and 2 x 2 taps inside the 2 x 2 halo.  OFF by default (BG_NN16_HALO_K3S2=1
+    // turns it on): measured on config 3 at batch 256, tap kernel -> this form: 64^2 96 <- 192: 0.435 -> 0.402 ms per call,
+    // 32^2 192 <- 384: 0.29 -> 0.37 - a block of the 1-tap phase loads a 17 x 17 halo and stores a full patch for a
+    // quarter of the MFMA work, so the halo's saving in L2 -> LDS bytes does not pay.
+    if (g.stride == 2 && g.k == 3 && g.pad == 1 && g.pstep == 2 && zdim == 4) {
+        const char* e3 = getenv("BG_NN16_HALO_K3S2");
+        return (e3 && atoi(e3) == 1) ? 2 : 0;
+    }
     return 0;
 }
 
