@@ -580,6 +580,128 @@ template <int NT, int NF> constexpr int nn16h_lds_bytes() {
     return ring > epi ? ring : epi;
 }
 
+// Epilogue of the halo-tile kernels (both forms): accumulators -> LDS [128][BN + 4] fp32 (two halves of the patch) ->
+// 16-byte row segments.
+// p.stats_part (batch-norm statistics of the OUTPUT, fused: ops.py:630 tf.nn.moments of the tensor this launch writes):
+// every stored value, as rounded to its stored type, is written back into the staging tile; the block then reduces the
+// tile's columns to one row of per-channel partial sums [sum | sum of squares] - summed over blocks in a fixed order by
+// bn_partial_finalize, no atomics.
+struct NHTile {                     // which patch / column tile / phase a block owns
+    int b, y0, x0, n0, ph, pw, phase, nph, tx, ty, tiles_x, tiles_y;
+};
+template <int NF, int THIN>
+__device__ __forceinline__ void nn16h_epilogue(const NN16Params& p, const NHTile& tl, f32x4_t (&acc)[4][NF],
+                                               unsigned char* smem) {
+    constexpr int BN = 32 * NF;
+    const Gather& g = p.g;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int px = lane & 15, kb = lane >> 4;
+    const int b = tl.b, y0 = tl.y0, x0 = tl.x0, n0 = tl.n0, ph = tl.ph, pw = tl.pw, phase = tl.phase, nph = tl.nph;
+    const int tx = tl.tx, ty = tl.ty, tiles_x = tl.tiles_x, tiles_y = tl.tiles_y;
+    constexpr int ELD = BN + 4;
+    float* est = reinterpret_cast<float*>(smem);
+    const float alpha = p.alpha ? *p.alpha : 1.0f;
+    constexpr int CPR = BN / 8;
+    constexpr int RG = 512 / BN;                        // row groups of the column reduction (threads RG * BN .. 511 idle)
+    for (int half = 0; half < 2; ++half) {
+        if ((wm >> 1) == half) {                        // waves of pixel rows 8 half .. 8 half + 7
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const int row = ((wm & 1) * 4 + i) * 16 + px;
+                    const int col = wn * 16 * NF + 16 * j + 4 * kb;
+                    f32x4_t v = acc[i][j];
+                    v[0] *= alpha; v[1] *= alpha; v[2] *= alpha; v[3] *= alpha;
+                    *reinterpret_cast<f32x4_t*>(est + row * ELD + col) = v;
+                }
+        }
+        __syncthreads();
+        for (int idx = t; idx < 128 * CPR; idx += 512) {
+            const int row = idx / CPR, cc = idx - row * CPR;
+            const int gy = y0 + 8 * half + (row >> 4), gx = x0 + (row & 15);
+            const int col = THIN == 1 ? 0 : n0 + cc * 8;
+            const int oy = THIN == 1 ? 2 * gy + (cc >> 1) : gy * g.pstep + ph;
+            const int ox = THIN == 1 ? 2 * gx + (cc & 1) : gx * g.pstep + pw;
+            f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(est + row * ELD + cc * 8);
+            f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(est + row * ELD + cc * 8 + 4);
+            const bool live = gy < g.Hq && gx < g.Wq && col < p.N && oy < g.Ho && ox < g.Wo;
+            if (live) {
+                const int64_t ooff = ((int64_t)(b * g.Ho + oy) * g.Wo + ox) * p.out_ld + col;
+                if (p.bias) {
+                    v0 += *reinterpret_cast<const f32x4_t*>(p.bias + col);
+                    v1 += *reinterpret_cast<const f32x4_t*>(p.bias + col + 4);
+                }
+                if (p.out_f32) {
+                    float* o = reinterpret_cast<float*>(p.out) + ooff;
+                    if (p.accumulate) {
+                        v0 += *reinterpret_cast<const f32x4_t*>(o);
+                        v1 += *reinterpret_cast<const f32x4_t*>(o + 4);
+                    }
+                    *reinterpret_cast<f32x4_t*>(o) = v0;
+                    *reinterpret_cast<f32x4_t*>(o + 4) = v1;
+                } else {
+                    __bf16* o = reinterpret_cast<__bf16*>(p.out) + ooff;
+                    if (p.accumulate) {
+                        const uint4 rr = *reinterpret_cast<const uint4*>(o);
+                        v0[0] += bf16_lo(rr.x); v0[1] += bf16_hi(rr.x); v0[2] += bf16_lo(rr.y); v0[3] += bf16_hi(rr.y);
+                        v1[0] += bf16_lo(rr.z); v1[1] += bf16_hi(rr.z); v1[2] += bf16_lo(rr.w); v1[3] += bf16_hi(rr.w);
+                    }
+                    uint4 rr;
+                    rr.x = pack_bf16x2(v0[0], v0[1]);
+                    rr.y = pack_bf16x2(v0[2], v0[3]);
+                    rr.z = pack_bf16x2(v1[0], v1[1]);
+                    rr.w = pack_bf16x2(v1[2], v1[3]);
+                    *reinterpret_cast<uint4*>(o) = rr;
+                    if (p.stats_part) {                 // the values as stored
+                        v0[0] = bf16_lo(rr.x); v0[1] = bf16_hi(rr.x); v0[2] = bf16_lo(rr.y); v0[3] = bf16_hi(rr.y);
+                        v1[0] = bf16_lo(rr.z); v1[1] = bf16_hi(rr.z); v1[2] = bf16_lo(rr.w); v1[3] = bf16_hi(rr.w);
+                    }
+                }
+            } else if (p.stats_part) {
+                v0 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                v1 = v0;
+            }
+            if (p.stats_part) {
+                *reinterpret_cast<f32x4_t*>(est + row * ELD + cc * 8) = v0;
+                *reinterpret_cast<f32x4_t*>(est + row * ELD + cc * 8 + 4) = v1;
+            }
+        }
+        __syncthreads();
+        if (p.stats_part) {                             // (block-uniform)
+            // column sums of this half's 128 stored rows -> partial row 2 * block + half
+            float st_s = 0.f, st_q = 0.f;
+            if (t < RG * BN) {
+                const int colr = t % BN;
+                for (int row = t / BN; row < 128; row += RG) {
+                    const float v = est[row * ELD + colr];
+                    st_s += v;
+                    st_q = fmaf(v, v, st_q);
+                }
+            }
+            __syncthreads();                            // every read of the tile is done: reuse its first rows
+            if (t < RG * BN) {
+                est[t] = st_s;
+                est[RG * BN + t] = st_q;
+            }
+            __syncthreads();
+            if (t < BN && n0 + t < p.N) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int r2 = 0; r2 < RG; ++r2) {
+                    s += est[r2 * BN + t];
+                    q += est[RG * BN + r2 * BN + t];
+                }
+                const int64_t prow = 2 * ((((int64_t)b * tiles_y + ty) * tiles_x + tx) * nph + phase) + half;
+                p.stats_part[prow * (2 * (int64_t)p.N) + n0 + t] = s;
+                p.stats_part[prow * (2 * (int64_t)p.N) + p.N + n0 + t] = q;
+            }
+            __syncthreads();                            // (the next half overwrites the tile)
+        }
+    }
+}
+
 // THIN = 1 (r03): the input gradient of a 3 x 3 stride-2 (pad 1) convolution whose INPUT has 8 channels (the image layers of
 // the discriminator) as ONE stride-1 2 x 2-window launch: the 2 x 2 output pixels (2 y + py, 2 x + px) of source pixel
 // window (y .. y + 1, x .. x + 1) are the 4 x 8 = 32 output columns of a tile (tap k = p + 1 - 2 w per axis, a zero weight
@@ -798,114 +920,22 @@ __global__ __launch_bounds__(512, 4) void nn16h_kernel(const NN16Params p) {    
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // ---- epilogue: accumulators -> LDS [128][BN + 4] fp32 (two halves of the patch) -> 16-byte row segments ----
-    // p.stats_part (batch-norm statistics of the OUTPUT, fused: ops.py:630 tf.nn.moments of the tensor this launch writes):
-    // every stored value, as rounded to its stored type, is written back into the staging tile; the block then reduces the
-    // tile's columns to one row of per-channel partial sums [sum | sum of squares] - summed over blocks in a fixed order by
-    // bn_partial_finalize, no atomics.
-    constexpr int ELD = BN + 4;
-    float* est = reinterpret_cast<float*>(smem);
-    const float alpha = p.alpha ? *p.alpha : 1.0f;
-    constexpr int CPR = BN / 8;
-    constexpr int RG = 512 / BN;                        // row groups of the column reduction (threads RG * BN .. 511 idle)
-    for (int half = 0; half < 2; ++half) {
-        if ((wm >> 1) == half) {                        // waves of pixel rows 8 half .. 8 half + 7
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NF; ++j) {
-                    const int row = ((wm & 1) * 4 + i) * 16 + px;
-                    const int col = wn * 16 * NF + 16 * j + 4 * kb;
-                    f32x4_t v = acc[i][j];
-                    v[0] *= alpha; v[1] *= alpha; v[2] *= alpha; v[3] *= alpha;
-                    *reinterpret_cast<f32x4_t*>(est + row * ELD + col) = v;
-                }
-        }
-        __syncthreads();
-        for (int idx = t; idx < 128 * CPR; idx += 512) {
-            const int row = idx / CPR, cc = idx - row * CPR;
-            const int gy = y0 + 8 * half + (row >> 4), gx = x0 + (row & 15);
-            const int col = THIN == 1 ? 0 : n0 + cc * 8;
-            const int oy = THIN == 1 ? 2 * gy + (cc >> 1) : gy * g.pstep + ph;
-            const int ox = THIN == 1 ? 2 * gx + (cc & 1) : gx * g.pstep + pw;
-            f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(est + row * ELD + cc * 8);
-            f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(est + row * ELD + cc * 8 + 4);
-            const bool live = gy < g.Hq && gx < g.Wq && col < p.N && oy < g.Ho && ox < g.Wo;
-            if (live) {
-                const int64_t ooff = ((int64_t)(b * g.Ho + oy) * g.Wo + ox) * p.out_ld + col;
-                if (p.bias) {
-                    v0 += *reinterpret_cast<const f32x4_t*>(p.bias + col);
-                    v1 += *reinterpret_cast<const f32x4_t*>(p.bias + col + 4);
-                }
-                if (p.out_f32) {
-                    float* o = reinterpret_cast<float*>(p.out) + ooff;
-                    if (p.accumulate) {
-                        v0 += *reinterpret_cast<const f32x4_t*>(o);
-                        v1 += *reinterpret_cast<const f32x4_t*>(o + 4);
-                    }
-                    *reinterpret_cast<f32x4_t*>(o) = v0;
-                    *reinterpret_cast<f32x4_t*>(o + 4) = v1;
-                } else {
-                    __bf16* o = reinterpret_cast<__bf16*>(p.out) + ooff;
-                    if (p.accumulate) {
-                        const uint4 rr = *reinterpret_cast<const uint4*>(o);
-                        v0[0] += bf16_lo(rr.x); v0[1] += bf16_hi(rr.x); v0[2] += bf16_lo(rr.y); v0[3] += bf16_hi(rr.y);
-                        v1[0] += bf16_lo(rr.z); v1[1] += bf16_hi(rr.z); v1[2] += bf16_lo(rr.w); v1[3] += bf16_hi(rr.w);
-                    }
-                    uint4 rr;
-                    rr.x = pack_bf16x2(v0[0], v0[1]);
-                    rr.y = pack_bf16x2(v0[2], v0[3]);
-                    rr.z = pack_bf16x2(v1[0], v1[1]);
-                    rr.w = pack_bf16x2(v1[2], v1[3]);
-                    *reinterpret_cast<uint4*>(o) = rr;
-                    if (p.stats_part) {                 // the values as stored
-                        v0[0] = bf16_lo(rr.x); v0[1] = bf16_hi(rr.x); v0[2] = bf16_lo(rr.y); v0[3] = bf16_hi(rr.y);
-                        v1[0] = bf16_lo(rr.z); v1[1] = bf16_hi(rr.z); v1[2] = bf16_lo(rr.w); v1[3] = bf16_hi(rr.w);
-                    }
-                }
-            } else if (p.stats_part) {
-                v0 = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                v1 = v0;
-            }
-            if (p.stats_part) {
-                *reinterpret_cast<f32x4_t*>(est + row * ELD + cc * 8) = v0;
-                *reinterpret_cast<f32x4_t*>(est + row * ELD + cc * 8 + 4) = v1;
-            }
-        }
-        __syncthreads();
-        if (p.stats_part) {                             // (block-uniform)
-            // column sums of this half's 128 stored rows -> partial row 2 * block + half
-            float st_s = 0.f, st_q = 0.f;
-            if (t < RG * BN) {
-                const int colr = t % BN;
-                for (int row = t / BN; row < 128; row += RG) {
-                    const float v = est[row * ELD + colr];
-                    st_s += v;
-                    st_q = fmaf(v, v, st_q);
-                }
-            }
-            __syncthreads();                            // every read of the tile is done: reuse its first rows
-            if (t < RG * BN) {
-                est[t] = st_s;
-                est[RG * BN + t] = st_q;
-            }
-            __syncthreads();
-            if (t < BN && n0 + t < p.N) {
-                float s = 0.f, q = 0.f;
-#pragma unroll
-                for (int r2 = 0; r2 < RG; ++r2) {
-                    s += est[r2 * BN + t];
-                    q += est[RG * BN + r2 * BN + t];
-                }
-                const int64_t prow = 2 * ((((int64_t)b * tiles_y + ty) * tiles_x + tx) * nph + phase) + half;
-                p.stats_part[prow * (2 * (int64_t)p.N) + n0 + t] = s;
-                p.stats_part[prow * (2 * (int64_t)p.N) + p.N + n0 + t] = q;
-            }
-            __syncthreads();                            // (the next half overwrites the tile)
-        }
-    }
+    NHTile tl;
+    tl.b = b; tl.y0 = y0; tl.x0 = x0; tl.n0 = n0; tl.ph = ph; tl.pw = pw; tl.phase = phase; tl.nph = nph;
+    tl.tx = tx; tl.ty = ty; tl.tiles_x = tiles_x; tl.tiles_y = tiles_y;
+    nn16h_epilogue<NF, THIN>(p, tl, acc, smem);
 }
 
+// ------------------------------------------------------------------------------------------
+// Measured and rejected (r03): a second form of the halo kernel - 32-channel chunks (64-byte pixel rows), TWO halo buffers so
+// that the next chunk streams in during the current one, two K items per step with their weight tiles issued two steps
+// ahead through a 3-slot ring, counted waits (s_waitcnt vmcnt(issued - needed) per wave, nothing drained), 74 - 78 KB of LDS.
+// Bit-identical results, config 3 at batch 256: 101.6 -> 106.9 ms per iteration; transposed conv 192 -> 96 at 128^2:
+// 3.1 -> 4.4 ms.  A block computes a 32-channel chunk of a 2 x 2 window in ~0.6 us and a halo tile takes ~2 us to arrive: one
+// chunk of look-ahead hides less than the single 64-channel buffer of the first form loses, and the 64-byte rows halve the
+// coalescing of the DMA's global reads.  Hiding the latency needs ~3 tiles in flight per block, which two blocks per CU
+// cannot hold in 160 KB.  (The 64-byte-row swizzle that is conflict-free for ds_read_b128's lane groups, should it be
+// needed again: chunk c of row r at c ^ ((r >> 1) & 2).)
 // ------------------------------------------------------------------------------------------
 // TN kernel (weight gradients): K = pixels, both operands pixel-major in LDS, transposed operand reads
 // ------------------------------------------------------------------------------------------

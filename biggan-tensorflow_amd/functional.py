@@ -324,9 +324,11 @@ def _thin_plan(x, cin, cout):
     cost 16.8 of 137 ms per config-3 iteration at batch 256 (r02 kernel stats) for 0.3 % of the FLOPs."""
     if not Precision.resident or x.dtype not in (BF16, torch.float32) or os.environ.get("BG_IMAGE_LAYERS", "") == "fp32":
         return None                      # (BG_IMAGE_LAYERS=fp32: A/B switch, the fp32-tensor kernels of round 1)
-    if cin < 8 and cout % 8 == 0:
+    # (the thin side and its rounding residual share the 8 channels: at most 4; a 5 ... 7-channel side - the attention
+    #  projections of a ch = 40 / 48 / 56 model - takes the fp32-tensor kernels like any other odd channel count)
+    if cin <= 4 and cout % 8 == 0:
         return "in"
-    if cout < 8 and cin % 8 == 0 and x.dtype == BF16:
+    if cout <= 4 and cin % 8 == 0 and x.dtype == BF16:
         return "out"
     return None
 

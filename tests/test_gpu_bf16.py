@@ -318,6 +318,29 @@ def test_regulariser_never_reads_the_packed_weights_of_an_earlier_run():
         Fn.set_precision("fp32")
 
 
+def test_bf16_mode_with_attention_projections_of_six_channels():
+    """--ch 48 --precision bf16: the f / g projections of the attention blocks have 48 / 8 = 6 channels - neither a multiple
+    of 8 (bf16-resident kernels) nor <= 4 (the hi | lo form of the 3-channel image layers); they take the fp32-tensor
+    kernels.  One D op and one G op against the fp32 mode of the same model: losses within 2e-2."""
+    from tests.common import make_args
+    from biggan_tensorflow_amd import model, scope as S, functional as Fn
+    try:
+        out = {}
+        for prec in ("fp32", "bf16"):
+            gan = model.BigGAN(make_args(img_size=64, ch=48, batch_size=2, z_dim=64, precision=prec),
+                               store=S.VariableStore("cuda", seed=3)).build_model()
+            gen = torch.Generator(device="cuda").manual_seed(1)
+            real = torch.rand(2, 64, 64, 3, device="cuda", generator=gen) * 2 - 1
+            z = torch.randn(2, 64, device="cuda", generator=gen)
+            d = gan.d_step(real, z, apply=False)
+            g_ = gan.g_step(2, z, apply=False)
+            out[prec] = (d["d_loss"].item(), g_["g_loss"].item())
+        for a, b in zip(out["fp32"], out["bf16"]):
+            assert np.isfinite(b) and abs(a - b) <= 2e-2 * abs(a), out
+    finally:
+        Fn.set_precision("fp32")
+
+
 @pytest.mark.parametrize("mode,img,ch,B", [("bf16-staged", 64, 16, 4), ("bf16", 64, 16, 4), ("bf16", 128, 64, 2)])
 def test_bf16_step_close_to_float64_oracle(mode, img, ch, B):
     """Whole D op and G op in the bf16 modes against the float64 oracle: losses within 2e-2 relative (SURVEY section
