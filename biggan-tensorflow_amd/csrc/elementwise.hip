@@ -413,41 +413,55 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_act_bwd_dx_kernel(
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, int per_sample,
-                                       double count, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ dalpha, float* __restrict__ cm, int N, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// 64 channels x 4 sample lanes per block: a thread walks every 4th sample with 8 loads in flight (one thread per channel
+// walking all N samples was N / 8 dependent memory round trips: 36 us per launch at N = 256, 11 launches per iteration)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                              int per_sample, double count, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ dalpha,
+                                                              float* __restrict__ cm, int N, int C) {
+    __shared__ double red[5][4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const bool live = c < C;
     const float* p0 = part;
     const float* p1 = part + (int64_t)N * C;
     const float* p2 = part + 2 * (int64_t)N * C;
     double s0 = 0, s1 = 0, s2 = 0, g0 = 0, g1 = 0;
-    // 8 samples' loads in flight per thread (a plain loop is one dependent memory round trip per sample)
-    for (int n0 = 0; n0 < N; n0 += 8) {
-        float a[8], b[8], d[8], ga[8];
+    if (live) {
+        for (int n0 = ry; n0 < N; n0 += 32) {
+            float a[8], b[8], d[8], ga[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int n = n0 + u < N ? n0 + u : N - 1;
-            a[u] = p0[(int64_t)n * C + c];
-            b[u] = p1[(int64_t)n * C + c];
-            d[u] = p2[(int64_t)n * C + c];
-            ga[u] = gamma[(per_sample ? (int64_t)n * C : 0) + c];
-        }
+            for (int u = 0; u < 8; ++u) {
+                const int n = n0 + 4 * u < N ? n0 + 4 * u : N - 1;
+                a[u] = p0[(int64_t)n * C + c];
+                b[u] = p1[(int64_t)n * C + c];
+                d[u] = p2[(int64_t)n * C + c];
+                ga[u] = gamma[(per_sample ? (int64_t)n * C : 0) + c];
+            }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int n = n0 + u;
-            if (n >= N) break;
-            s0 += a[u];
-            s1 += b[u];
-            s2 += d[u];
-            g0 += (double)ga[u] * a[u];
-            g1 += (double)ga[u] * b[u];
-            if (per_sample) {
-                dbeta[(int64_t)n * C + c] = a[u];
-                dgamma[(int64_t)n * C + c] = b[u];
+            for (int u = 0; u < 8; ++u) {
+                const int n = n0 + 4 * u;
+                if (n >= N) break;
+                s0 += a[u];
+                s1 += b[u];
+                s2 += d[u];
+                g0 += (double)ga[u] * a[u];
+                g1 += (double)ga[u] * b[u];
+                if (per_sample) {
+                    dbeta[(int64_t)n * C + c] = a[u];
+                    dgamma[(int64_t)n * C + c] = b[u];
+                }
             }
         }
     }
+    red[0][ry][cx] = s0; red[1][ry][cx] = s1; red[2][ry][cx] = s2; red[3][ry][cx] = g0; red[4][ry][cx] = g1;
+    __syncthreads();
+    if (ry != 0 || !live) return;
+    s0 = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
+    s1 = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
+    s2 = (red[2][0][cx] + red[2][1][cx]) + (red[2][2][cx] + red[2][3][cx]);
+    g0 = (red[3][0][cx] + red[3][1][cx]) + (red[3][2][cx] + red[3][3][cx]);
+    g1 = (red[4][0][cx] + red[4][1][cx]) + (red[4][2][cx] + red[4][3][cx]);
     if (!per_sample) {
         dbeta[c] = (float)s0;
         dgamma[c] = (float)s1;
@@ -986,6 +1000,50 @@ __global__ __launch_bounds__(EW_BLOCK) void pad_channels_kernel(const TS* __rest
             if (mode == 1) v -= (float)(__bf16)v;
         }
         dst[idx] = (TD)v;
+    }
+}
+
+// The image layers' two hot cases of pad_channels_kernel, one PIXEL per thread (the generic kernel spends two 64-bit
+// divisions and a 2-byte store per element: 1 TB/s on a 230 MB job):
+//   fp32 [pixels, Cs <= 4] -> bf16 [pixels, 8] (modes 0 / 1 / 2: zero fill, hi | lo split, duplicate), one 16-byte store;
+//   fp32 [pixels, 8] -> TD [pixels, Cd <= 4] (mode 3: fold the two halves), two 16-byte loads.
+__global__ __launch_bounds__(EW_BLOCK) void pad_pixels_to8_kernel(const float* __restrict__ src, __bf16* __restrict__ dst,
+                                                                  int64_t pixels, int Cs, int mode) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * EW_BLOCK) {
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = 0.f;
+        const float* sp = src + i * Cs;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < Cs) {
+                const float s = sp[c];
+                if (mode == 1) {
+                    const float hi = (float)(__bf16)s;
+                    v[c] = hi;
+                    v[c + Cs] = s - hi;
+                } else {
+                    v[c] = s;
+                    if (mode == 2) v[c + Cs] = s;
+                }
+            }
+        typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+        bf16x8v o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (__bf16)v[c];
+        *reinterpret_cast<bf16x8v*>(dst + i * 8) = o;
+    }
+}
+template <class TD>
+__global__ __launch_bounds__(EW_BLOCK) void fold_pixels_from8_kernel(const float* __restrict__ src, TD* __restrict__ dst,
+                                                                     int64_t pixels, int Cd) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * EW_BLOCK) {
+        const float4 a = *reinterpret_cast<const float4*>(src + i * 8);
+        const float4 b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < Cd) dst[i * Cd + c] = (TD)(v[c] + v[c + Cd]);
     }
 }
 
@@ -2118,7 +2176,7 @@ int bg_bn_apply_act_bwd_reduce(const float* x, const float* dy, const float* mea
 int bg_bn_bwd_finalize(const float* part, const float* gamma, int per_sample, double count, float* dgamma, float* dbeta,
                        float* dalpha, float* cm, int N, int C, void* stream) {
     BG_REQUIRE(part && gamma && dgamma && dbeta && cm && N > 0 && C > 0 && count > 0, "bg_bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), part, gamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, as_stream(stream), part, gamma,
                        per_sample, count, dgamma, dbeta, dalpha, cm, N, C);
     BG_LAUNCH_CHECK();
     return BG_OK;
@@ -2153,6 +2211,49 @@ int bg_prelu_fwd(const float* x, const float* alpha, float* y, int64_t rows, int
     return BG_OK;
 }
 
+// d alpha of a PReLU on a tensor with C <= 4 channels (the discriminator's activation of the IMAGE, ops.py:299): the column
+// skeleton would put 3 threads of a row-lane on a row (4-byte loads, 0.6 TB/s); here a thread owns whole pixels, 4 in flight.
+__global__ __launch_bounds__(EW_BLOCK) void prelu_dalpha_thin_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                     float* __restrict__ dalpha, int64_t rows, int C) {
+    __shared__ float red[4][EW_BLOCK];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t stride = (int64_t)gridDim.x * EW_BLOCK;
+    int64_t r = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    for (; r + 3 * stride < rows; r += 4 * stride) {
+        float xv[4][4], gv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < C) {
+                    xv[u][c] = x[(r + u * stride) * C + c];
+                    gv[u][c] = dy[(r + u * stride) * C + c];
+                }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < C) acc[c] += xv[u][c] < 0.f ? gv[u][c] * xv[u][c] : 0.f;
+    }
+    for (; r < rows; r += stride)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) {
+                const float xs = x[r * C + c];
+                acc[c] += xs < 0.f ? dy[r * C + c] * xs : 0.f;
+            }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[c][threadIdx.x] = acc[c];
+    __syncthreads();
+    for (int s = EW_BLOCK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + s];
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < C) atomicAdd(&dalpha[threadIdx.x], red[threadIdx.x][0]);
+}
+
 int bg_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx, float* dalpha, int64_t rows, int C,
                  void* stream) {
     BG_REQUIRE(x && dy && alpha && rows > 0 && C > 0, "bg_prelu_bwd: bad argument");
@@ -2167,6 +2268,12 @@ int bg_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx,
         BG_LAUNCH_CHECK();
     }
     if (dalpha) {
+        if (C <= 4 && rows >= (int64_t(1) << 16)) {
+            hipLaunchKernelGGL(prelu_dalpha_thin_kernel, dim3(256), dim3(EW_BLOCK), 0, as_stream(stream), x, dy, dalpha, rows,
+                               C);
+            BG_LAUNCH_CHECK();
+            return BG_OK;
+        }
         PreluDalphaFn fn{x, dy, C};
         launch_colreduce<1>(fn, dalpha, (int64_t)C, rows, 1, C, as_stream(stream));
         BG_LAUNCH_CHECK();
@@ -2575,6 +2682,24 @@ int bg_pad_channels(const void* src, int src_dtype, void* dst, int dst_dtype, in
     BG_REQUIRE(mode == 0 || ((mode == 1 || mode == 2) && Cd >= 2 * Cs) || (mode == 3 && Cs >= 2 * Cd),
                "bg_pad_channels: mode %d does not fit %d -> %d channels", mode, Cs, Cd);
     const int64_t total = outer * Cd * inner;
+    if (inner == 1 && src_dtype == BG_F32 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
+        if (dst_dtype == BG_BF16 && Cd == 8 && Cs <= 4 && mode != 3) {            // image / image-gradient -> 8 channels
+            hipLaunchKernelGGL(pad_pixels_to8_kernel, dim3(ew_grid(outer)), dim3(EW_BLOCK), 0, as_stream(stream),
+                               (const float*)src, (__bf16*)dst, outer, Cs, mode);
+            BG_LAUNCH_CHECK();
+            return BG_OK;
+        }
+        if (mode == 3 && Cs == 8 && Cd <= 4) {                                      // fold of the fp32 8-channel result
+            if (dst_dtype == BG_F32)
+                hipLaunchKernelGGL((fold_pixels_from8_kernel<float>), dim3(ew_grid(outer)), dim3(EW_BLOCK), 0,
+                                   as_stream(stream), (const float*)src, (float*)dst, outer, Cd);
+            else
+                hipLaunchKernelGGL((fold_pixels_from8_kernel<__bf16>), dim3(ew_grid(outer)), dim3(EW_BLOCK), 0,
+                                   as_stream(stream), (const float*)src, (__bf16*)dst, outer, Cd);
+            BG_LAUNCH_CHECK();
+            return BG_OK;
+        }
+    }
     BG_DISPATCH_XY(src_dtype, dst_dtype,
                    hipLaunchKernelGGL((pad_channels_kernel<TX, TY>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0,
                                       as_stream(stream), (const TX*)src, (TY*)dst, total, Cs, Cd, inner, mode));

@@ -687,7 +687,7 @@ def test_symmetrize(c):
     assert np.array_equal(t2n(out), (ac + ac.t()).cpu().numpy())
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 8, 3), (4, 4, 4, 64), (7, 33)])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 3), (4, 4, 4, 64), (7, 33), (5, 128, 128, 3), (70001, 1)])
 def test_prelu(shape):
     Fn = _fn()
     rng = np.random.default_rng(len(shape))
@@ -703,6 +703,50 @@ def test_prelu(shape):
     assert rel_err(t2n(y), yr.detach().numpy()) < 1e-6
     assert rel_err(t2n(xc.grad), xt.grad.numpy()) < 1e-6
     assert rel_err(t2n(ac.grad), at.grad.numpy()) < 5e-5
+
+
+@pytest.mark.parametrize("cs", [1, 3, 4])
+def test_pad_channels_pixel_forms_match_the_generic_kernel(cs):
+    """bg_pad_channels: the one-pixel-per-thread kernels of the image layers (fp32 [pixels, C <= 4] -> bf16 [pixels, 8] in
+    the zero-fill / hi | lo split / duplicate modes; fold of an fp32 [pixels, 8] result to C channels, fp32 or bf16) against
+    the definition - and against the generic kernel, which a mis-aligned view still takes."""
+    from biggan_tensorflow_amd import hip
+    L = hip.lib()
+    rng = np.random.default_rng(cs)
+    pixels = 3 * 37 * 41
+    x = torch.tensor(rng.standard_normal((pixels + 1, cs)), dtype=torch.float32, device="cuda")
+    for mode in (hip.PAD_ZERO_FILL, hip.PAD_SPLIT, hip.PAD_DUP):
+        if mode != hip.PAD_ZERO_FILL and 2 * cs > 8:
+            continue
+        xs = x[:pixels]
+        ref = torch.zeros(pixels, 8, dtype=torch.float32, device="cuda")
+        hi = xs.to(torch.bfloat16).float()
+        if mode == hip.PAD_ZERO_FILL:
+            ref[:, :cs] = xs
+        elif mode == hip.PAD_SPLIT:
+            ref[:, :cs] = hi
+            ref[:, cs:2 * cs] = xs - hi
+        else:
+            ref[:, :cs] = xs
+            ref[:, cs:2 * cs] = xs
+        ref = ref.to(torch.bfloat16)
+        got = torch.empty(pixels, 8, dtype=torch.bfloat16, device="cuda")
+        hip.check(L.bg_pad_channels(hip.ptr(xs), hip.F32, hip.ptr(got), hip.BF16, pixels, cs, 8, 1, mode, hip.stream()))
+        assert torch.equal(got, ref), mode
+        if cs % 4:                              # a view that starts one row later is not 16-byte aligned: generic kernel
+            xo = x[1:]
+            got2 = torch.empty(pixels, 8, dtype=torch.bfloat16, device="cuda")
+            hip.check(L.bg_pad_channels(hip.ptr(xo), hip.F32, hip.ptr(got2), hip.BF16, pixels, cs, 8, 1, mode, hip.stream()))
+            got3 = torch.empty(pixels, 8, dtype=torch.bfloat16, device="cuda")
+            xa = xo.clone()
+            hip.check(L.bg_pad_channels(hip.ptr(xa), hip.F32, hip.ptr(got3), hip.BF16, pixels, cs, 8, 1, mode, hip.stream()))
+            assert torch.equal(got2, got3), mode
+    if 2 * cs <= 8:
+        y8 = torch.tensor(rng.standard_normal((pixels, 8)), dtype=torch.float32, device="cuda")
+        for dt_t, dt_h in ((torch.float32, hip.F32), (torch.bfloat16, hip.BF16)):
+            out = torch.empty(pixels, cs, dtype=dt_t, device="cuda")
+            hip.check(L.bg_pad_channels(hip.ptr(y8), hip.F32, hip.ptr(out), dt_h, pixels, 8, cs, 1, hip.PAD_FOLD, hip.stream()))
+            assert torch.equal(out, (y8[:, :cs] + y8[:, cs:2 * cs]).to(dt_t))
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 8, 16), (3, 4, 6, 5), (1, 2, 2, 64)])
