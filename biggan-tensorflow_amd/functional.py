@@ -221,7 +221,9 @@ class ZeroPool:
     the following runs (retired buffers stay referenced: a captured HIP graph may still address them)."""
 
     def __init__(self, device, nbytes=1 << 19):
-        self.device = torch.device(device)
+        # (the INDEXED device, as tensors report it: torch.device("cuda") != torch.device("cuda:0"), and a pool that never
+        #  matched its callers' x.device silently handed every request to torch.zeros - bench.py builds its model on "cuda")
+        self.device = torch.empty(0, device=device).device
         self.cap = int(nbytes)
         self.bufs = [None, None]
         self.used = [0, 0]          # bytes handed out from each buffer in its last run (= what the next clear covers)

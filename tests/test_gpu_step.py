@@ -745,6 +745,30 @@ def test_hip_graph_replay_matches_eager_iterations():
             assert got <= max(1e-5, 4.0 * floor, 8.0 * dw), (k, got, "eager-vs-eager", floor, "weight moved by", dw)
 
 
+def test_zero_pool_serves_a_model_built_on_the_unindexed_device():
+    """The per-run zero pool compares its device with the callers' x.device: a model built on "cuda" (bench.py, main.py)
+    must get its accumulators from the pool like one built on "cuda:0" - torch.device("cuda") != torch.device("cuda:0")
+    once silently sent every request to torch.zeros (~70 extra fill launches per iteration)."""
+    from tests.common import make_args
+    from biggan_tensorflow_amd import model, scope as S, functional as Fn
+    gan = model.BigGAN(make_args(img_size=64, ch=8, batch_size=2, z_dim=64), device="cuda",
+                       store=S.VariableStore("cuda", seed=1)).build_model()
+    calls = []
+    orig = torch.zeros
+
+    def counting_zeros(*a, **k):
+        calls.append(a)
+        return orig(*a, **k)
+    gan.train_step(gan.synthetic_batch(2))          # (first run: creates the pool's buffers)
+    torch.zeros = counting_zeros
+    try:
+        gan.train_step(gan.synthetic_batch(2))
+    finally:
+        torch.zeros = orig
+    assert gan._zero_pool.want > 0 and gan._zero_pool.device == gan.g_arena.params.device
+    assert len(calls) <= 4, ("accumulators still come from torch.zeros", len(calls))
+
+
 def test_two_models_in_one_process_do_not_share_variables():
     """The ops resolve variables through a process-wide default store (one TF graph in the reference); every
     run re-binds it to the model that is stepping, so two models can be trained side by side."""
