@@ -799,6 +799,7 @@ class SaFrontFn(Function):
 
     @staticmethod
     def forward(ctx, x, wf, wg, wh, bf_, bg_, bh_):
+        ctx.fork = getattr(x, "bg_fork", None)
         x = _c(x)
         B, H, W_, C = x.shape
         grp = wf.bg_group
@@ -856,9 +857,12 @@ class SaFrontFn(Function):
                                    f32(delta), stream()))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            # (the block's input forks into this projection and the gated residual: the residual's gradient - the block's
+            #  incoming gradient itself, left in the fork state by ScaleAddFn.backward - is the buffer accumulated into)
+            dx, add = _fork_target(ctx.fork, x)
             ws, nb = hip.scratch(L.bg_conv2d_dgrad_workspace_bytes, cd, dev)
-            check(L.bg_conv2d_dgrad(cd, act(dy), act(grp.pack_p), None, act(dx), 0, f32(ws), nb, stream()))
+            check(L.bg_conv2d_dgrad(cd, act(dy), act(grp.pack_p), None, act(dx), int(add), f32(ws), nb, stream()))
+            _fork_done(ctx.fork, dx)
         if not _Mode.inputs_only:
             need_w = any(w.requires_grad for w in (wf, wg, wh))
             if need_w:
@@ -1530,6 +1534,7 @@ class ScaleAddFn(Function):
 
     @staticmethod
     def forward(ctx, o, gamma, x):
+        ctx.fork = getattr(x, "bg_fork", None)
         o, x = _c(o), _c(x)
         ctx.o_dtype = o.dtype
         if o.dtype != x.dtype:
@@ -1565,6 +1570,11 @@ class ScaleAddFn(Function):
         ctx.o = None
         if do is not None:
             do = cast(do, ctx.o_dtype)
+        # the residual's gradient IS dy: when x is a forked tensor, the other branch's input-gradient kernel adds into this
+        # very buffer (every read of dy above is already enqueued; the tensor was handed to this node alone) and
+        # ForkFn.backward then sees one storage twice - no separate sum
+        if ctx.needs_input_grad[2] and dy.dtype == ctx.o_dtype:
+            _fork_done(ctx.fork, dy)
         return do, dg, dy
 
 
