@@ -930,6 +930,29 @@ class PackGroup:
         self.pack_p, self.pack_t, self.offsets = pack_p, pack_t, []
 
 
+def sn_shard_layout(numels, rows, cols, world):
+    """Who iterates which weight under data parallelism, and where its results live (SnBatch(shard=...)).  Pure host
+    arithmetic: ``owner[i]`` by longest-processing-time assignment on the weight sizes; ``place[i]`` = (owner, offsets of
+    sigma | u | v_hat inside the owner's segment of the flat state buffer, in floats, each padded to 4); ``fill[r]`` = floats
+    rank r's segment uses (the segment length is their maximum, so that one all-gather moves every segment)."""
+    pad4 = lambda k: (k + 3) // 4 * 4                                  # noqa: E731
+    n = len(numels)
+    load = [0] * world
+    owner = [0] * n
+    for i in sorted(range(n), key=lambda i: (-numels[i], i)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[i] = r
+        load[r] += numels[i]
+    fill = [0] * world
+    place = []
+    for i in range(n):
+        r = owner[i]
+        o = fill[r]
+        place.append((r, o, o + 4, o + 4 + pad4(cols[i])))
+        fill[r] = o + 4 + pad4(cols[i]) + pad4(rows[i])
+    return owner, place, fill
+
+
 class SnBatch:
     """Every spectrally-normalised weight of one network in one multi-tensor call (4 launches forward,
     2 backward) instead of a kernel chain per weight.  ``forward()`` runs the power iteration of all
@@ -997,20 +1020,7 @@ class SnBatch:
         state_views = None
         if shard is not None:
             rank, world, _ = shard
-            pad4 = lambda k: (k + 3) // 4 * 4                                  # noqa: E731
-            load = [0] * world
-            self.owner = [0] * n
-            for i in sorted(range(n), key=lambda i: (-self.w[i].numel(), i)):
-                r = min(range(world), key=lambda q: (load[q], q))
-                self.owner[i] = r
-                load[r] += self.w[i].numel()
-            fill = [0] * world
-            place = []
-            for i in range(n):
-                r = self.owner[i]
-                o = fill[r]
-                place.append((r, o, o + 4, o + 4 + pad4(self.cols[i])))       # sigma | u | v_hat of item i inside r's segment
-                fill[r] = o + 4 + pad4(self.cols[i]) + pad4(self.rows[i])
+            self.owner, place, fill = sn_shard_layout([w.numel() for w in self.w], self.rows, self.cols, world)
             self.seg = max(max(fill), 4)
             self.state_flat = torch.zeros(world * self.seg, dtype=torch.float32, device=dev)
             state_views = []
@@ -2044,7 +2054,23 @@ class OrthoCosineRegFn(Function):
         def prod(out):
             o2 = out.view(rows, c)
             S_ = torch.empty_like(dA)
-            check(lib().bg_symmetrize(f32(dA), f32(S_), c, stream()))
+            L = lib()
+            check(L.bg_symmetrize(f32(dA), f32(S_), c, stream()))
+            wn = getattr(w, "bg_sn_wn", None)
+            pk = getattr(wn, "bg_pack_p", None) if wn is not None else None
+            if (Precision.resident and pk is not None and getattr(wn, "bg_run_stamp", None) is current_run_stamp()
+                    and c % 8 == 0 and rows % 8 == 0 and os.environ.get("BG_REG_GRAM", "") != "fp32"):
+                # bf16-resident mode: W (dA + dA^T) = sigma (W / sigma) S on the bf16-resident GEMM - the packed copy of
+                # this run's spectral norm as a [rows, c] "image" of a 1 x 1 convolution whose kernel is S (symmetric, so its
+                # packed [n][c] form is S itself).  Same operand precision as the staged kernel it replaces (which rounds the
+                # fp32 W and S to bf16 while staging), about twice its rate.
+                S16 = cast(S_, BF16)
+                gs = torch.empty(1, dtype=torch.float32, device=dA.device)
+                check(L.bg_scale_dev(f32(g), f32(wn.bg_sigma), f32(gs), 1, stream()))
+                cd = hip.conv_desc(1, rows, 1, c, rows, 1, c, 1, 1, 0, hip.PAD_ZERO, hip.COMPUTE_BF16, hip.BF16, hip.F32, 1)
+                ws, nb = hip.scratch(L.bg_conv2d_fwd_workspace_bytes, cd, dA.device)
+                check(L.bg_conv2d_fwd(cd, act(pk), act(S16), None, f32(gs), act(o2), 0, f32(ws), nb, stream()))
+                return
             gemm(W2, S_, o2, rows, c, c, c, c, c, alpha_dev=g)                                  # W dA + W dA^T = W (dA + dA^T)
         dw = param_grad(w, ctx.needs_input_grad[0], prod)
         ctx.w = ctx.dA = None

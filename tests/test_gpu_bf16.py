@@ -287,6 +287,42 @@ def test_bf16_staged_regulariser_and_large_gemm():
         Fn.set_precision("fp32")
 
 
+@pytest.mark.parametrize("shape", [(3, 3, 128, 256), (4, 4, 64, 96), (1, 1, 192, 24)])
+def test_regulariser_gradient_from_the_packed_weights(shape):
+    """bf16-resident mode: loss AND gradient of the ortho-cosine regulariser from the packed bf16 copy of w / sigma that
+    this run's spectral-norm batch wrote (Gram on bg_gram16, W (dA + dA^T) = sigma (W / sigma) S as a 1 x 1 convolution on
+    the bf16-resident GEMM) against the float64 reference; the fp32-Gram form (BG_REG_GRAM=fp32) agrees with it."""
+    import biggan_tensorflow_amd  # noqa: F401
+    from biggan_tensorflow_amd import functional as Fn, ops
+    from oracle import ref_ops as R
+    Fn.set_precision("bf16")
+    try:
+        rng = np.random.default_rng(shape[2])
+        w0 = rng.standard_normal(shape) * 0.05
+        wt = torch.tensor(w0, requires_grad=True)
+        ref = R.ortho_reg_loss(wt, 1e-4, "ortho_cosine")
+        ref.backward()
+        grads = {}
+        for form in ("", "fp32"):
+            if form:
+                os.environ["BG_REG_GRAM"] = form
+            w = cu(w0, True)
+            u = cu(rng.standard_normal((1, shape[-1])))
+            sb = Fn.SnBatch([(w, u)])
+            ops.begin_run()
+            sb.forward(Fn.current_run_stamp())
+            loss = Fn.OrthoCosineRegFn.apply(w, 1e-4)
+            loss.backward()
+            assert abs(loss.item() - ref.item()) <= 2e-2 * abs(ref.item()), (form, loss.item(), ref.item())
+            grads[form] = t2n(w.grad)
+            e = rel_err(grads[form], wt.grad.numpy())
+            assert e < 3e-2, (form, e)
+        assert rel_err(grads[""], grads["fp32"]) < 3e-2
+    finally:
+        os.environ.pop("BG_REG_GRAM", None)
+        Fn.set_precision("fp32")
+
+
 def test_regulariser_never_reads_the_packed_weights_of_an_earlier_run():
     """bf16-resident mode: the ortho-cosine regulariser takes its Gram matrix from the packed bf16 copy of w / sigma that the
     spectral-norm batch of THIS run wrote.  Evaluated in a run without that prefetch (after the weights changed) it must

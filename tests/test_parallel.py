@@ -138,3 +138,45 @@ def test_dp_gradient_identity_numpy():
     full = (per_sample / 8).sum(0)
     shards = [(per_sample[lo:hi] / 8).sum(0) for lo, hi in ((0, 4), (4, 8))]
     np.testing.assert_allclose(sum(shards), full, rtol=1e-13)
+
+
+def test_eight_rank_partitions_are_complete_and_disjoint():
+    """The 8-GPU run cannot be rehearsed here; what it partitions can: (a) ShardedRanges for every rank of world 8 on an
+    arena cut at stage boundaries - the owned sub-ranges tile every exchange range exactly once, in rank order (what the
+    in-place reduce-scatter / all-gather require: rank r's piece starts at lo + r * len / world); (b) the spectral-norm
+    ownership - every weight has exactly one owner, the segments of a rank's sigma | u | v_hat do not overlap, loads are
+    balanced to within the largest weight."""
+    import random
+    from biggan_tensorflow_amd.parallel import ShardedRanges
+    from biggan_tensorflow_amd.functional import sn_shard_layout
+    world = 8
+    size = 64 * 1237
+    bounds = [64 * 100, 64 * 400, 64 * 401, 64 * 900]
+    per_rank = [ShardedRanges(size, bounds, world, r, max_elems=64 * 256) for r in range(world)]
+    assert all(s.sharded and s.ranges == per_rank[0].ranges for s in per_rank)
+    covered = 0
+    for lo, hi in per_rank[0].ranges:
+        assert (hi - lo) % world == 0 and hi - lo <= 64 * 256
+        pieces = [s.owned(lo, hi) for s in per_rank]
+        step = (hi - lo) // world
+        assert pieces == [(lo + r * step, lo + (r + 1) * step) for r in range(world)]
+        covered += hi - lo
+    assert covered == size and per_rank[0].ranges[0][0] == 0 and per_rank[0].ranges[-1][1] == size
+    # spectral norm: config-3-like weight list (k*k*Cin x Cout kernels, dense layers, 1 x 1 attention projections)
+    rnd = random.Random(3)
+    shapes = [(9 * cin, cout) for cin, cout in ((1536, 1536), (1536, 768), (768, 768), (768, 384), (384, 384), (384, 192),
+                                                (192, 192), (192, 96), (96, 96))] * 3
+    shapes += [(16 * 1536, 768), (16 * 768, 384), (20, 24576), (148, 1536), (96, 12), (96, 48), (1536, 1)] * 2
+    rnd.shuffle(shapes)
+    rows, cols = [s[0] for s in shapes], [s[1] for s in shapes]
+    numels = [a * b for a, b in shapes]
+    owner, place, fill = sn_shard_layout(numels, rows, cols, world)
+    assert len(owner) == len(shapes) and set(owner) == set(range(world))
+    load = [sum(n for n, o in zip(numels, owner) if o == r) for r in range(world)]
+    assert max(load) - min(load) <= max(numels)
+    for r in range(world):
+        spans = sorted((o_s, o_v + (rows[i] + 3) // 4 * 4) for i, (rr, o_s, o_u, o_v) in enumerate(place) if rr == r)
+        assert spans[0][0] == 0 and spans[-1][1] == fill[r]
+        assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+    for i, (rr, o_s, o_u, o_v) in enumerate(place):
+        assert rr == owner[i] and o_u == o_s + 4 and o_v == o_u + (cols[i] + 3) // 4 * 4
