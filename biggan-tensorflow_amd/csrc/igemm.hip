@@ -925,8 +925,14 @@ struct Tag {
     double bytes = 0.0;     // algorithmic HBM bytes of the call: both activation tensors once in their stored type, the
                             // weights once (2 bytes packed / 4 bytes fp32) or, for a weight gradient, written once in fp32
     Tag(const char* op, const BgConvDesc* d) {
-        snprintf(s, sizeof(s), "%s N%d H%d Cin%d Cout%d Ho%d k%d s%d", op, d->N, d->H, d->Cin, d->Cout, d->Ho, d->k,
-                 d->stride);
+        // a 1 x 1 "convolution" over an [H, 1] column of ONE image is a plain matrix product through this entry point (the
+        // regulariser's W (dA + dA^T) from the packed weights): its own class, so that the measurement does not count it
+        // among the convolutions whose FLOPs SURVEY 8(d) defines
+        if (d->N == 1 && d->W == 1 && d->Wo == 1 && d->k == 1)
+            snprintf(s, sizeof(s), "gemm16 M%d N%d K%d (%s)", d->H, d->Cout, d->Cin, op);
+        else
+            snprintf(s, sizeof(s), "%s N%d H%d Cin%d Cout%d Ho%d k%d s%d", op, d->N, d->H, d->Cin, d->Cout, d->Ho, d->k,
+                     d->stride);
         const bool wgrad = strstr(op, "wgrad") != nullptr;
         const double sx = d->x_dtype == BG_BF16 ? 2.0 : 4.0, sy = d->y_dtype == BG_BF16 ? 2.0 : 4.0;
         const double sw = wgrad ? 4.0 : (d->w_packed ? 2.0 : 4.0);
