@@ -752,12 +752,12 @@ def test_bf16_step_matches_the_bf16_rounded_oracle(img, ch, B, seed, tol, med_to
         batch = RM.synthetic_batch(tr.cfg, seed, B)
         hip0 = gan.store.export_arrays()
 
-        def compare(tag, run_oracle, run_hip, loss_key):
+        def compare(tag, run_oracle, run_hip, loss_key, probe_oracle):
             tr.vs.state_updates.clear()
             gan.store.load_arrays(hip0, reset_ema=False)
             R.ROUND.on = True
             try:
-                ro, ho, flips = _kink_sync(tr, run_oracle, run_hip, near=KINK_NEAR)
+                ro, ho, flips = _kink_sync(tr, run_oracle, run_hip, near=KINK_NEAR, probe_oracle=probe_oracle)
             finally:
                 R.ROUND.on = False
             from tests import test_gpu_step as TS
@@ -794,11 +794,13 @@ def test_bf16_step_matches_the_bf16_rounded_oracle(img, ch, B, seed, tol, med_to
             compare("D op",
                     lambda: tr.d_step(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"], apply=False),
                     lambda: gan.d_step(cu(batch["real"]), cu(batch["z_d"]), dev_draws(batch["aug_real"]),
-                                       dev_draws(batch["aug_fake_d"]), apply=False), "d_loss")
+                                       dev_draws(batch["aug_fake_d"]), apply=False), "d_loss",
+                    lambda: tr.d_forward(batch["real"], batch["z_d"], batch["aug_real"], batch["aug_fake_d"]))
         if "G" in which:
             compare("G op",
                     lambda: tr.g_step(batch["z_g"], batch["aug_fake_g"], apply=False),
-                    lambda: gan.g_step(B, cu(batch["z_g"]), dev_draws(batch["aug_fake_g"]), apply=False), "g_loss")
+                    lambda: gan.g_step(B, cu(batch["z_g"]), dev_draws(batch["aug_fake_g"]), apply=False), "g_loss",
+                    lambda: tr.g_forward(batch["z_g"], batch["aug_fake_g"]))
     finally:
         R.ROUND.on = False
         Fn.set_precision("fp32")

@@ -172,15 +172,22 @@ def _applied_kink_synced(tr, gan, hip_state, dry_oracle, dry_hip, run_oracle, ru
     return ro, run_hip()
 
 
-def _kink_sync(tr, run_oracle, run_hip, rerun=True, near=1e-5):
+def _kink_sync(tr, run_oracle, run_hip, rerun=True, near=1e-5, probe_oracle=None):
     """``near``: how close to 0 (relative to the tensor's rms) a pre-activation must be for a differing side of the kink
-    to count as rounding (fp32 product: 1e-5; the bf16-resident product against the bf16-rounded oracle: bf16 ulps)."""
+    to count as rounding (fp32 product: 1e-5; the bf16-resident product against the bf16-rounded oracle: bf16 ulps).
+    ``probe_oracle``: a forward-only form of the oracle's op for the recording pass (the pre-activations are all that pass
+    is for; at config-3 widths a float64 backward is 30 s) - the full ``run_oracle`` then runs once, with the flips."""
     from oracle import ref_ops as R
     from biggan_tensorflow_amd import functional as Fn
     R.KINK.record, R.KINK.flip = [], None
     Fn.KinkProbe.sites = []
     try:
-        ro = run_oracle()
+        if probe_oracle is not None:
+            with torch.no_grad():
+                probe_oracle()
+            ro = None
+        else:
+            ro = run_oracle()
         ho = run_hip()
     finally:
         rec, R.KINK.record = R.KINK.record, None
@@ -217,16 +224,19 @@ def _kink_sync(tr, run_oracle, run_hip, rerun=True, near=1e-5):
                 flips[scope] = per_call
     if not ok:
         EXEMPT["kink_unsynced_ops"] += 1          # (relu / lrelu activations, gradient-penalty passes: no site names)
+        if ro is None:
+            tr.vs.state_updates.clear()
+            ro = run_oracle()
         return ro, ho, {}
     if total:
         EXEMPT["kink_elements"] += total
-        if rerun:
-            tr.vs.state_updates.clear()
-            R.KINK.flip = flips
-            try:
-                ro = run_oracle()
-            finally:
-                R.KINK.flip = None
+    if (total and rerun) or ro is None:
+        tr.vs.state_updates.clear()
+        R.KINK.flip = flips if total else None
+        try:
+            ro = run_oracle()
+        finally:
+            R.KINK.flip = None
     return ro, ho, flips
 
 
