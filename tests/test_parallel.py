@@ -85,6 +85,54 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_exchange(rank, world, port, q):
+    """The sharded update's data movement alone, for a larger world: in-place reduce-scatter of every exchange range, update
+    of the owned 1 / world, in-place all-gather - on the dedicated process group."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    parallel.init_from_env(backend="gloo")
+    pg2 = parallel.new_gradient_group()
+    size = 64 * 203
+    sh = parallel.ShardedRanges(size, [64 * 40, 64 * 41, 64 * 150], world, rank, max_elems=64 * 32)
+    gen = torch.Generator().manual_seed(11)
+    p0 = torch.randn(size, generator=gen)
+    g_all = [torch.randn(size, generator=gen) for _ in range(world)]
+    p, g = p0.clone(), g_all[rank].clone()
+    works = [(a, b, parallel.reduce_scatter_range(g, a, b, sh, pg2, async_op=True)) for a, b in sh.ranges]
+    gathers = []
+    for a, b, wk in works:
+        wk.wait()
+        oa, ob = sh.owned(a, b)
+        p[oa:ob] -= 0.5 * g[oa:ob]
+        gathers.append(parallel.all_gather_range(p, a, b, sh, pg2, async_op=True))
+    for wk in gathers:
+        wk.wait()
+    ok = sh.sharded and torch.allclose(p, p0 - 0.5 * sum(g_all), atol=1e-5)
+    # every rank ends with the SAME parameters, bit for bit (they all received the owners' bytes)
+    digest = float(p.double().sum())
+    q.put((rank, bool(ok), digest))
+    dist.destroy_process_group()
+
+
+def test_gloo_world8_sharded_exchange():
+    """Eight ranks (the driver's scaling run) over gloo on CPU: the in-place reduce-scatter / all-gather on arena ranges that
+    divide by 8, on the second process group."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_exchange, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(world)) and all(r[1] for r in res)
+    assert len({r[2] for r in res}) == 1
+
+
 def test_gloo_world2_allreduce_and_sharding():
     world = 2
     ctx = mp.get_context("spawn")
